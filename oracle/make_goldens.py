@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""Pin the oracle against the reference itself and freeze golden vectors.
+
+AUTHORING-CONTAINER ONLY (needs /root/reference).  Run:  python -m oracle.make_goldens
+
+What it does
+  1. puts oracle/_standin (a local `torchvision` stand-in; the real package is not
+     installed) ahead of /root/reference on sys.path and imports the reference's own
+     nerf_qa.DISTS_pytorch.DISTS_pt.DISTS and nerf_qa.ADISTS.ADISTS;
+  2. injects the deterministic VGG weights of nerf_qa_amd.synth into the stand-in
+     and assigns alpha/beta from the reference's weights.pt (what DISTS_pt.py:63,79-80
+     would do with sys.prefix/weights.pt);
+  3. runs the reference on seeded synthetic frame pairs, runs oracle/ on the same
+     inputs, REQUIRES them to agree (max-abs 2e-6 on scores; features bit-exact),
+  4. writes tests/golden/*.npz (inputs are regenerated from seeds; only outputs and
+     small summaries are stored) and nerf_qa_amd/data/dists_alpha_beta.npz (the
+     published DISTS alpha/beta as a data fixture).
+
+The reference source never enters the repo; only its numeric outputs do.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+from nerf_qa_amd import synth  # noqa: E402
+from oracle import adists_oracle, dists_oracle  # noqa: E402
+
+# (name, H, W, seeds, kinds)
+DISTS_CASES = [
+    ("64x64", 64, 64, (0, 1, 2, 3), None),
+    ("97x131", 97, 131, (10, 11, 12, 13), None),
+    ("256x256", 256, 256, (20, 21, 22, 23), None),
+    ("256x341", 256, 341, (30, 31), ("blur", "noise10")),
+    ("20x20", 20, 20, (40, 41), ("noise10", "indep")),
+    ("same64", 64, 64, (50,), ("same",)),
+]
+ADISTS_CASES = [
+    ("64x64", 64, 64, (0, 1), ("noise10", "blur")),
+    ("97x131", 97, 131, (10, 11), ("noise02", "indep")),
+    ("256x256", 256, 256, (20, 21), ("blur", "noise10")),
+    ("20x20", 20, 20, (40, 41), ("noise10", "indep")),       # every stage takes the global fallback
+    ("352x336", 352, 336, (60,), ("blur",)),                  # stage 5 is 22x21: windowed everywhere
+]
+WEIGHT_SEED = 1234
+
+
+def import_reference():
+    sys.path.insert(0, os.path.join(ROOT, "oracle", "_standin"))
+    sys.path.insert(1, REF)
+    import torchvision.models as tvm
+    np_convs = synth.vgg16_weights(WEIGHT_SEED)
+    tvm.WEIGHT_PROVIDER = lambda: np_convs
+    from nerf_qa.ADISTS import ADISTS as RefADISTS
+    from nerf_qa.DISTS_pytorch.DISTS_pt import DISTS as RefDISTS
+    return RefDISTS, RefADISTS, np_convs
+
+
+def feat_summary(feats):
+    return np.array([[f.mean().item(), f.abs().mean().item(), f.abs().max().item()] for f in feats], np.float64)
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(os.cpu_count())
+    RefDISTS, RefADISTS, np_convs = import_reference()
+    convs = dists_oracle.convs_from_numpy(np_convs)
+    ab = torch.load(os.path.join(REF, "nerf_qa", "DISTS_pytorch", "weights.pt"))
+    alpha, beta = ab["alpha"].float(), ab["beta"].float()
+    os.makedirs(os.path.join(ROOT, "nerf_qa_amd", "data"), exist_ok=True)
+    np.savez(os.path.join(ROOT, "nerf_qa_amd", "data", "dists_alpha_beta.npz"),
+             alpha=alpha.numpy().reshape(-1), beta=beta.numpy().reshape(-1))
+
+    ref_d = RefDISTS(load_weights=False).eval()
+    ref_d.alpha.data = alpha.clone()
+    ref_d.beta.data = beta.clone()
+    ref_a = RefADISTS().eval()
+    gold = os.path.join(ROOT, "tests", "golden")
+    os.makedirs(gold, exist_ok=True)
+
+    for name, h, w, seeds, kinds in DISTS_CASES:
+        xn, yn = synth.frame_batch(seeds, h, w, kinds)
+        x, y = torch.from_numpy(xn), torch.from_numpy(yn)
+        with torch.no_grad():
+            r_score = ref_d(x, y)
+            r_f0, r_f1 = ref_d.forward_once(x), ref_d.forward_once(y)
+            r_ff = ref_d.forward_from_feats(r_f0, r_f1)
+            r_avg = ref_d(x, y, batch_average=True)
+        o_f0, o_f1 = dists_oracle.vgg_pyramid(x, convs), dists_oracle.vgg_pyramid(y, convs)
+        for a, b in zip(r_f0 + r_f1, o_f0 + o_f1):
+            assert torch.equal(a, b), f"{name}: oracle pyramid differs from reference"
+        s1, s2 = dists_oracle.dists_stats(o_f0, o_f1)
+        o_score = dists_oracle.dists_score(s1, s2, alpha, beta)
+        d = (o_score - r_score).abs().max().item()
+        assert d <= 2e-6, f"{name}: oracle score differs from reference by {d}"
+        assert (r_ff - r_score).abs().max().item() <= 1e-6
+        o_avg = dists_oracle.dists(x, y, convs, alpha, beta, batch_average=True)
+        assert abs(o_avg.item() - r_avg.item()) <= 2e-6
+        print(f"DISTS {name:8s} ref={r_score.numpy()} |oracle-ref|={d:.2e}")
+        np.savez(os.path.join(gold, f"dists_{name}.npz"),
+                 h=h, w=w, seeds=np.array(seeds), kinds=np.array(kinds if kinds else synth.KINDS[:4]),
+                 weight_seed=WEIGHT_SEED, score=r_score.numpy(), score_avg=r_avg.numpy(),
+                 s1=s1.numpy(), s2=s2.numpy(), feat_x=feat_summary(r_f0), feat_y=feat_summary(r_f1))
+
+    for name, h, w, seeds, kinds in ADISTS_CASES:
+        xn, yn = synth.frame_batch(seeds, h, w, kinds)
+        x, y = torch.from_numpy(xn), torch.from_numpy(yn)
+        with torch.no_grad():
+            r_score = ref_a(x, y, as_loss=False)
+            r_loss = ref_a(x, y, as_loss=True)
+        o_score = adists_oracle.adists(x, y, convs, as_loss=False)
+        o_loss = adists_oracle.adists(x, y, convs, as_loss=True)
+        d = (o_score - r_score).abs().max().item()
+        assert d <= 2e-6, f"{name}: A-DISTS oracle differs from reference by {d}"
+        assert abs(o_loss.item() - r_loss.item()) <= 2e-6
+        print(f"ADISTS {name:8s} ref={r_score.numpy()} |oracle-ref|={d:.2e}")
+        np.savez(os.path.join(gold, f"adists_{name}.npz"),
+                 h=h, w=w, seeds=np.array(seeds), kinds=np.array(kinds), weight_seed=WEIGHT_SEED,
+                 score=r_score.numpy(), loss=r_loss.numpy())
+
+    # weight fingerprint so a drift of the generator is caught on the GPU box too
+    fp = np.array([[float(np.abs(w_).sum()), float(b_.sum())] for w_, b_ in np_convs])
+    np.savez(os.path.join(gold, "vgg_fingerprint.npz"), weight_seed=WEIGHT_SEED, fp=fp)
+    print("goldens written to", gold)
+
+
+if __name__ == "__main__":
+    main()
