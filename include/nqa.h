@@ -1,0 +1,149 @@
+/*
+ * nqa.h -- C ABI of libnqa_hip.so: the DISTS / A-DISTS hot path of kobejean/nerf-qa
+ * as hand-written HIP kernels for MI355X (gfx950).
+ *
+ * The reference has no FFI: its boundary for this path is the Python callable
+ * surface of two nn.Modules.  Each entry point below names
+ * the reference lines whose arithmetic it replaces; nerf_qa_amd/ (the Python
+ * shell that mirrors those modules) is the only intended caller and binds these
+ * symbols with ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - plain C types only; every pointer marked "dev" is a device pointer owned by
+ *     the caller (e.g. a torch tensor's data_ptr()); "host" pointers are host memory;
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream).  Kernels
+ *     are enqueued on it and the call returns without synchronising;
+ *   - return value: 0 on success, a negative NQA_E_* code on failure, with a
+ *     message available from nqa_last_error() (thread-local);
+ *   - no global mutable state besides the thread-local error string and the
+ *     optional timing ring (nqa_timing_*), so calls are re-entrant per stream.
+ *
+ * Layouts
+ *   - images enter as the reference's tensors: float32 NCHW, values in [0,1];
+ *   - activations inside the pyramid are NHWC in the element type of the chosen
+ *     precision (`prec`): NQA_PREC_F32 float, NQA_PREC_BF16 bfloat16, NQA_PREC_F16
+ *     IEEE half.  All accumulation and all statistics are float32/float64;
+ *   - VGG weights are handed over once as a packed blob (nqa_pack_vgg_weights).
+ */
+#ifndef NQA_H
+#define NQA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NQA_VERSION 1
+
+enum { NQA_PREC_F32 = 0, NQA_PREC_BF16 = 1, NQA_PREC_F16 = 2 };
+
+enum {
+  NQA_OK = 0,
+  NQA_E_ARG = -1,       /* bad argument (null pointer, non-positive size, unknown prec) */
+  NQA_E_SHAPE = -2,     /* shape the kernels do not support */
+  NQA_E_WORKSPACE = -3, /* workspace too small */
+  NQA_E_LAUNCH = -4     /* HIP reported an error when enqueuing */
+};
+
+#define NQA_NUM_CONVS 13
+#define NQA_NUM_TAPS 6
+#define NQA_TOTAL_CHNS 1475 /* 3+64+128+256+512+512, DISTS_pt.py:57 */
+
+int nqa_version(void);
+const char *nqa_last_error(void);
+
+/* ---- VGG-16 weights -------------------------------------------------------- */
+
+/* Bytes of the packed weight blob for `prec`. */
+size_t nqa_packed_weights_bytes(int prec);
+
+/* Pack the 13 conv3x3 layers (torchvision features[0,2,5,7,10,12,14,17,19,21,24,26,28],
+ * sliced into stages at DISTS_pt.py:36-49) from float32 OIHW host arrays into the
+ * kernel-native blob (host memory, nqa_packed_weights_bytes(prec) bytes).  The caller
+ * then copies the blob to the device once. */
+int nqa_pack_vgg_weights(const float *const w_host[NQA_NUM_CONVS], const float *const b_host[NQA_NUM_CONVS],
+                         int prec, void *packed_host);
+
+/* ---- single operators (used by forward_once and by the parity tests) ------- */
+
+/* conv1_1 with the input normalisation folded in front: h=(x-mean)/std (DISTS_pt.py:92),
+ * zero padding applied to h, conv3x3(3->64)+bias+ReLU (features[0,1]).  x: dev float32
+ * NCHW (n,3,H,W); out: dev NHWC (n,H,W,64) in prec's element type. */
+int nqa_conv1_1(const float *x_nchw, int n, int H, int W, const void *packed_w, int prec, void *out_nhwc,
+                void *stream);
+
+/* conv3x3 stride 1 pad 1 + bias + ReLU for VGG layer `layer` (1..12), NHWC in/out
+ * (torchvision Conv2d+ReLU pairs, DISTS_pt.py:36-49). */
+int nqa_conv3x3_relu(const void *in_nhwc, int n, int H, int W, int layer, const void *packed_w, int prec,
+                     void *out_nhwc, void *stream);
+
+/* L2pooling.forward, DISTS_pt.py:22-25 (= Downsample, ADISTS.py:28-31):
+ * sqrt(depthwise 3x3 Hanning, stride 2, pad 1, of x^2, + 1e-12).  NHWC (n,H,W,C) ->
+ * (n,ceil(H/2),ceil(W/2),C). */
+int nqa_l2pool(const void *in_nhwc, int n, int H, int W, int C, int prec, void *out_nhwc, void *stream);
+
+/* NHWC (prec element type) -> float32 NCHW, so forward_once can return the
+ * reference's tensor format (DISTS_pt.py:103). */
+int nqa_nhwc_to_nchw_f32(const void *in_nhwc, int n, int H, int W, int C, int prec, float *out_nchw, void *stream);
+
+/* ---- the fused paths --------------------------------------------------------- */
+
+/* Workspace bytes needed by nqa_vgg_pyramid / nqa_dists_forward for `n_images`
+ * images (2*B for a batch of B pairs) of H x W. */
+size_t nqa_workspace_bytes(int n_images, int H, int W, int prec);
+
+/* forward_once, DISTS_pt.py:91-103, for n images: runs the 13 convs and 4 L2-pools.
+ * taps[k] (k=0..4, dev, may not be null) receives relu{1_2,2_2,3_3,4_3,5_3} as NHWC
+ * in prec's element type with shape (n, Hk, Wk, Ck), Hk = ceil(H / 2^k). */
+int nqa_vgg_pyramid(const float *x_nchw, int n, int H, int W, const void *packed_w, int prec, void *workspace,
+                    size_t workspace_bytes, void *const taps[5], void *stream);
+
+/* DISTS.forward up to the per-channel similarities, DISTS_pt.py:105-141:
+ * both pyramids (x and y, B images each, float32 NCHW (B,3,H,W)), then for every
+ * (b, stage, channel) S1 = (2 mx my + 1e-6)/(mx^2 + my^2 + 1e-6) and
+ * S2 = (2 cov + 1e-6)/(vx + vy + 1e-6).  s1, s2: dev float32 (B, 1475). */
+int nqa_dists_forward(const float *x_nchw, const float *y_nchw, int B, int H, int W, const void *packed_w, int prec,
+                      void *workspace, size_t workspace_bytes, float *s1, float *s2, void *stream);
+
+/* The statistics alone on caller-provided float32 NCHW feature lists
+ * (forward_from_feats, DISTS_pt.py:181-202).  fx[k], fy[k]: dev (B, C[k], Hk[k], Wk[k]).
+ * scratch: dev, nqa_stats_scratch_bytes(B, total pixels...) bytes. */
+size_t nqa_stats_scratch_bytes(int B, const int C[NQA_NUM_TAPS], const int Hk[NQA_NUM_TAPS], const int Wk[NQA_NUM_TAPS]);
+int nqa_dists_stats_nchw(const float *const fx[NQA_NUM_TAPS], const float *const fy[NQA_NUM_TAPS], int B,
+                         const int C[NQA_NUM_TAPS], const int Hk[NQA_NUM_TAPS], const int Wk[NQA_NUM_TAPS],
+                         void *scratch, size_t scratch_bytes, float *s1, float *s2, void *stream);
+
+/* alpha/beta weighted sum -> score, DISTS_pt.py:127-129,135,142,144:
+ * w = sum(alpha)+sum(beta); score_b = 1 - sum_c alpha_c/w S1_bc - sum_c beta_c/w S2_bc.
+ * alpha, beta: dev float32 (1475).  score: dev float32 (B). */
+int nqa_dists_score(const float *s1, const float *s2, const float *alpha, const float *beta, int B, float *score,
+                    void *stream);
+
+/* ---- A-DISTS (ADISTS.forward, ADISTS.py:137-197, as_map=False) ------------------ */
+
+size_t nqa_adists_workspace_bytes(int B, int H, int W, int prec);
+
+/* Both pyramids, texture-probability maps from x (compute_prob, ADISTS.py:71-100),
+ * entropy channel weights from x (ADISTS.py:127-135,150-161), Gaussian-windowed (21x21,
+ * sigma 7, valid) or global T/S statistics per stage (ADISTS.py:165-183) and the
+ * weighted combine (ADISTS.py:185-191).  d: dev float32 (B) receives D (the caller
+ * returns 1-D or 1-mean(D), ADISTS.py:194-197). */
+int nqa_adists_forward(const float *x_nchw, const float *y_nchw, int B, int H, int W, const void *packed_w, int prec,
+                       void *workspace, size_t workspace_bytes, float *d, void *stream);
+
+/* ---- per-kernel timing (bench.py's roofline leg) -------------------------------- */
+
+/* When enabled, every launch of the conv / pool / stats kernels is bracketed by a
+ * pair of hipEvents recorded on the launch stream.  nqa_timing_collect synchronises
+ * those events and returns, per kernel class, the number of launches and the summed
+ * device time in milliseconds, then clears the ring. */
+enum { NQA_K_CONV1 = 0, NQA_K_CONV = 1, NQA_K_POOL = 2, NQA_K_STATS = 3, NQA_K_ADISTS = 4, NQA_K_COUNT = 5 };
+int nqa_timing_enable(int on);
+int nqa_timing_collect(int launches[NQA_K_COUNT], double ms[NQA_K_COUNT]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NQA_H */

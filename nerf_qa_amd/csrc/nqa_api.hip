@@ -1,0 +1,444 @@
+// extern "C" surface of libnqa_hip.so (include/nqa.h): error plumbing, timing ring,
+// weight packing, and the drivers that chain the kernels into forward_once /
+// DISTS.forward (nerf_qa/DISTS_pytorch/DISTS_pt.py:91-148).
+#include <stdarg.h>
+#include <string.h>
+
+#include <vector>
+
+#include "nqa_common.h"
+
+namespace nqa {
+
+// ---- errors ---------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int check_launch(const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return NQA_E_LAUNCH;
+  }
+  return NQA_OK;
+}
+
+// ---- timing ring ------------------------------------------------------------------
+static const int kRing = 16384;
+static bool g_timing = false;
+static std::vector<hipEvent_t> g_ev0, g_ev1;
+static std::vector<int> g_cls;
+static int g_used = 0;
+
+TimedLaunch::TimedLaunch(int kc, hipStream_t s) : kclass(kc), stream(s), slot(-1) {
+  if (!g_timing || g_used >= kRing) return;
+  if ((int)g_ev0.size() <= g_used) {
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+    g_ev0.push_back(a);
+    g_ev1.push_back(b);
+    g_cls.push_back(kc);
+  }
+  slot = g_used++;
+  g_cls[slot] = kc;
+  (void)hipEventRecord(g_ev0[slot], stream);
+}
+TimedLaunch::~TimedLaunch() {
+  if (slot >= 0) (void)hipEventRecord(g_ev1[slot], stream);
+}
+
+// ---- packed weight blob -------------------------------------------------------------
+static size_t layer_bytes(int layer, int prec) {
+  const ConvSpec &c = kConvs[layer];
+  if (layer == 0) return align_up(27 * 64 * 4 + 64 * 4, 256);
+  return align_up((size_t)c.cin * c.cout * 9 * prec_elem_bytes(prec), 256) + align_up((size_t)c.cout * 4, 256);
+}
+size_t layer_offset(int layer, int prec) {
+  size_t o = 0;
+  for (int l = 0; l < layer; ++l) o += layer_bytes(l, prec);
+  return o;
+}
+size_t layer_bias_offset(int layer, int prec) {
+  const ConvSpec &c = kConvs[layer];
+  if (layer == 0) return layer_offset(0, prec) + 27 * 64 * 4;
+  return layer_offset(layer, prec) + align_up((size_t)c.cin * c.cout * 9 * prec_elem_bytes(prec), 256);
+}
+
+static uint16_t f32_to_bf16(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+  return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);                    // round to nearest even
+}
+static uint16_t f32_to_f16(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  const uint32_t sign = (u >> 16) & 0x8000u;
+  u &= 0x7FFFFFFFu;
+  if (u >= 0x7F800000u) return (uint16_t)(sign | (u > 0x7F800000u ? 0x7E00u : 0x7C00u));
+  if (u >= 0x477FF000u) return (uint16_t)(sign | 0x7C00u);  // rounds to >= 65520 -> inf
+  if (u < 0x33000001u) return (uint16_t)sign;               // < 2^-25 (or == 2^-25 tie -> 0)
+  const int e = (int)(u >> 23) - 127;
+  uint32_t m = (u & 0x7FFFFFu) | 0x800000u;
+  int shift;
+  uint32_t base;
+  if (e < -14) {  // subnormal half
+    shift = 13 + (-14 - e);
+    base = 0;
+  } else {
+    shift = 13;
+    base = (uint32_t)(e + 15) << 10;
+    m &= 0x7FFFFFu;
+  }
+  uint32_t r = m >> shift;
+  const uint32_t rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+  if (rem > half || (rem == half && (r & 1u))) ++r;
+  return (uint16_t)(sign | (base + r));
+}
+
+// ---- drivers ----------------------------------------------------------------------------
+struct PyrDims {
+  int h[5], w[5];
+};
+static PyrDims pyr_dims(int H, int W) {
+  PyrDims d;
+  d.h[0] = H;
+  d.w[0] = W;
+  for (int k = 1; k < 5; ++k) {
+    d.h[k] = (d.h[k - 1] + 1) / 2;
+    d.w[k] = (d.w[k - 1] + 1) / 2;
+  }
+  return d;
+}
+
+static size_t act_bytes(int n, int H, int W, int prec) {
+  return align_up((size_t)n * H * W * 64 * prec_elem_bytes(prec), 256);
+}
+
+// Runs layers 1..12 and the four L2-pools on `n` images whose conv1_1 output sits in bufA.
+// Stage k's last conv writes into taps[k] when taps is given, else into the ping-pong pair.
+// on_tap(k, ptr, Hk, Wk, Ck) is called once that conv is enqueued.
+template <typename F>
+static int run_stages(void *bufA, void *bufB, int n, int H, int W, const void *packed, int prec, void *const *taps,
+                      F on_tap, hipStream_t st) {
+  const PyrDims d = pyr_dims(H, W);
+  void *cur = bufA;
+  int rc;
+  for (int layer = 1; layer < NQA_NUM_CONVS; ++layer) {
+    const ConvSpec &cs = kConvs[layer];
+    const int k = cs.stage;
+    void *dst = (cs.last && taps) ? taps[k] : (cur == bufA ? bufB : bufA);
+    if ((rc = conv3x3(cur, n, d.h[k], d.w[k], layer, packed, prec, dst, st))) return rc;
+    cur = dst;
+    if (cs.last) {
+      if ((rc = on_tap(k, cur, d.h[k], d.w[k], cs.cout))) return rc;
+      if (k < 4) {
+        void *pdst = (cur == bufA) ? bufB : bufA;
+        if ((rc = l2pool(cur, n, d.h[k], d.w[k], cs.cout, prec, pdst, st))) return rc;
+        cur = pdst;
+      }
+    }
+  }
+  return NQA_OK;
+}
+
+static bool bad_dims(const char *who, int n, int H, int W, int prec) {
+  if (n <= 0 || H <= 0 || W <= 0) {
+    set_error("%s: non-positive size n=%d H=%d W=%d", who, n, H, W);
+    return true;
+  }
+  if (prec != NQA_PREC_F32 && prec != NQA_PREC_BF16 && prec != NQA_PREC_F16) {
+    set_error("%s: unknown prec %d", who, prec);
+    return true;
+  }
+  if ((long)H * W * 512 >= (1L << 31)) {
+    set_error("%s: image too large for 32-bit in-image offsets (H*W*512 >= 2^31)", who);
+    return true;
+  }
+  return false;
+}
+
+struct StatsPlan {
+  StageDesc d;
+  size_t doubles;
+};
+static StatsPlan stats_plan(int B, const int *C, const int *HW, int nstage, int prec, bool stage0_nchw_only) {
+  StatsPlan p;
+  memset(&p, 0, sizeof(p));
+  long off = 0;
+  int coff = 0;
+  for (int k = 0; k < nstage; ++k) {
+    const bool nchw = stage0_nchw_only ? (k == 0) : true;
+    const int ppb = nchw ? stats_nchw_ppb(HW[k]) : stats_nhwc_ppb(C[k], prec);
+    p.d.part_off[k] = off;
+    p.d.nblk[k] = cdiv(HW[k], ppb);
+    p.d.hw[k] = HW[k];
+    p.d.c[k] = C[k];
+    p.d.coff[k] = coff;
+    off += (long)B * p.d.nblk[k] * C[k] * 5;
+    coff += C[k];
+  }
+  p.d.nstage = nstage;
+  p.d.ctot = coff;
+  p.doubles = (size_t)off;
+  return p;
+}
+
+}  // namespace nqa
+
+using namespace nqa;
+
+extern "C" {
+
+int nqa_version(void) { return NQA_VERSION; }
+const char *nqa_last_error(void) { return g_err; }
+
+int nqa_timing_enable(int on) {
+  g_timing = on != 0;
+  g_used = 0;
+  return NQA_OK;
+}
+
+int nqa_timing_collect(int launches[NQA_K_COUNT], double ms[NQA_K_COUNT]) {
+  for (int i = 0; i < NQA_K_COUNT; ++i) {
+    launches[i] = 0;
+    ms[i] = 0.0;
+  }
+  for (int s = 0; s < g_used; ++s) {
+    float t = 0.f;
+    if (hipEventSynchronize(g_ev1[s]) != hipSuccess || hipEventElapsedTime(&t, g_ev0[s], g_ev1[s]) != hipSuccess) {
+      set_error("timing_collect: event %d failed", s);
+      g_used = 0;
+      return NQA_E_LAUNCH;
+    }
+    launches[g_cls[s]] += 1;
+    ms[g_cls[s]] += (double)t;
+  }
+  g_used = 0;
+  return NQA_OK;
+}
+
+size_t nqa_packed_weights_bytes(int prec) { return layer_offset(NQA_NUM_CONVS, prec); }
+
+int nqa_pack_vgg_weights(const float *const w_host[NQA_NUM_CONVS], const float *const b_host[NQA_NUM_CONVS], int prec,
+                         void *packed_host) {
+  if (!w_host || !b_host || !packed_host) {
+    set_error("pack_vgg_weights: null pointer");
+    return NQA_E_ARG;
+  }
+  if (prec != NQA_PREC_F32 && prec != NQA_PREC_BF16 && prec != NQA_PREC_F16) {
+    set_error("pack_vgg_weights: unknown prec %d", prec);
+    return NQA_E_ARG;
+  }
+  char *blob = static_cast<char *>(packed_host);
+  memset(blob, 0, nqa_packed_weights_bytes(prec));
+  {  // layer 0: w0[k][co], k = (ky*3+kx)*3 + c, from OIHW
+    float *w0 = reinterpret_cast<float *>(blob + layer_offset(0, prec));
+    for (int co = 0; co < 64; ++co)
+      for (int c = 0; c < 3; ++c)
+        for (int t = 0; t < 9; ++t) w0[(t * 3 + c) * 64 + co] = w_host[0][(co * 3 + c) * 9 + t];
+    memcpy(blob + layer_bias_offset(0, prec), b_host[0], 64 * 4);
+  }
+  const int cpc = prec == NQA_PREC_F32 ? 4 : 8, kc = 4 * cpc;
+  for (int l = 1; l < NQA_NUM_CONVS; ++l) {
+    const ConvSpec &cs = kConvs[l];
+    const int bn = conv_bn(cs.cout), ncc = cs.cin / kc;
+    char *dst = blob + layer_offset(l, prec);
+    for (int ct = 0; ct < cs.cout / bn; ++ct)
+      for (int cc = 0; cc < ncc; ++cc)
+        for (int t = 0; t < 9; ++t)
+          for (int n = 0; n < bn; ++n)
+            for (int pos = 0; pos < 4; ++pos) {
+              const int c = pos ^ ((n >> 2) & 3);
+              const size_t e0 = (((((size_t)ct * ncc + cc) * 9 + t) * bn + n) * 4 + pos) * cpc;
+              for (int j = 0; j < cpc; ++j) {
+                const int cin = cc * kc + c * cpc + j, cout = ct * bn + n;
+                const float v = w_host[l][((size_t)cout * cs.cin + cin) * 9 + t];
+                if (prec == NQA_PREC_F32)
+                  reinterpret_cast<float *>(dst)[e0 + j] = v;
+                else
+                  reinterpret_cast<uint16_t *>(dst)[e0 + j] = prec == NQA_PREC_BF16 ? f32_to_bf16(v) : f32_to_f16(v);
+              }
+            }
+    memcpy(blob + layer_bias_offset(l, prec), b_host[l], (size_t)cs.cout * 4);
+  }
+  return NQA_OK;
+}
+
+int nqa_conv1_1(const float *x, int n, int H, int W, const void *packed, int prec, void *out, void *stream) {
+  if (!x || !packed || !out) {
+    set_error("conv1_1: null pointer");
+    return NQA_E_ARG;
+  }
+  if (bad_dims("conv1_1", n, H, W, prec)) return NQA_E_ARG;
+  return conv1_1(x, n, H, W, packed, prec, out, static_cast<hipStream_t>(stream));
+}
+
+int nqa_conv3x3_relu(const void *in, int n, int H, int W, int layer, const void *packed, int prec, void *out,
+                     void *stream) {
+  if (!in || !packed || !out) {
+    set_error("conv3x3_relu: null pointer");
+    return NQA_E_ARG;
+  }
+  if (layer < 1 || layer >= NQA_NUM_CONVS) {
+    set_error("conv3x3_relu: layer %d out of range 1..12", layer);
+    return NQA_E_ARG;
+  }
+  if (bad_dims("conv3x3_relu", n, H, W, prec)) return NQA_E_ARG;
+  return conv3x3(in, n, H, W, layer, packed, prec, out, static_cast<hipStream_t>(stream));
+}
+
+int nqa_l2pool(const void *in, int n, int H, int W, int C, int prec, void *out, void *stream) {
+  if (!in || !out) {
+    set_error("l2pool: null pointer");
+    return NQA_E_ARG;
+  }
+  if (bad_dims("l2pool", n, H, W, prec)) return NQA_E_ARG;
+  if (C <= 0 || C % 8) {
+    set_error("l2pool: C=%d must be a positive multiple of 8", C);
+    return NQA_E_SHAPE;
+  }
+  return l2pool(in, n, H, W, C, prec, out, static_cast<hipStream_t>(stream));
+}
+
+int nqa_nhwc_to_nchw_f32(const void *in, int n, int H, int W, int C, int prec, float *out, void *stream) {
+  if (!in || !out) {
+    set_error("nhwc_to_nchw: null pointer");
+    return NQA_E_ARG;
+  }
+  if (bad_dims("nhwc_to_nchw", n, H, W, prec) || C <= 0) return NQA_E_ARG;
+  return nhwc_to_nchw(in, n, H * W, C, prec, out, static_cast<hipStream_t>(stream));
+}
+
+size_t nqa_workspace_bytes(int n_images, int H, int W, int prec) {
+  if (n_images <= 0 || H <= 0 || W <= 0) return 0;
+  const PyrDims d = pyr_dims(H, W);
+  int C[6], HW[6];
+  C[0] = 3;
+  HW[0] = H * W;
+  for (int k = 0; k < 5; ++k) {
+    C[k + 1] = kChns[k + 1];
+    HW[k + 1] = d.h[k] * d.w[k];
+  }
+  const StatsPlan p = stats_plan((n_images + 1) / 2, C, HW, 6, prec, true);
+  return 2 * act_bytes(n_images, H, W, prec) + align_up(p.doubles * 8, 256);
+}
+
+int nqa_vgg_pyramid(const float *x, int n, int H, int W, const void *packed, int prec, void *ws, size_t ws_bytes,
+                    void *const taps[5], void *stream) {
+  if (!x || !packed || !ws || !taps) {
+    set_error("vgg_pyramid: null pointer");
+    return NQA_E_ARG;
+  }
+  for (int k = 0; k < 5; ++k)
+    if (!taps[k]) {
+      set_error("vgg_pyramid: taps[%d] is null", k);
+      return NQA_E_ARG;
+    }
+  if (bad_dims("vgg_pyramid", n, H, W, prec)) return NQA_E_ARG;
+  const size_t ab = act_bytes(n, H, W, prec);
+  if (ws_bytes < 2 * ab) {
+    set_error("vgg_pyramid: workspace %zu < %zu bytes", ws_bytes, 2 * ab);
+    return NQA_E_WORKSPACE;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  char *bufA = static_cast<char *>(ws), *bufB = bufA + ab;
+  int rc;
+  if ((rc = conv1_1(x, n, H, W, packed, prec, bufA, st))) return rc;
+  return run_stages(bufA, bufB, n, H, W, packed, prec, taps, [](int, void *, int, int, int) { return 0; }, st);
+}
+
+int nqa_dists_forward(const float *x, const float *y, int B, int H, int W, const void *packed, int prec, void *ws,
+                      size_t ws_bytes, float *s1, float *s2, void *stream) {
+  if (!x || !y || !packed || !ws || !s1 || !s2) {
+    set_error("dists_forward: null pointer");
+    return NQA_E_ARG;
+  }
+  if (bad_dims("dists_forward", B, H, W, prec)) return NQA_E_ARG;
+  const int n = 2 * B;
+  const size_t need = nqa_workspace_bytes(n, H, W, prec);
+  if (ws_bytes < need) {
+    set_error("dists_forward: workspace %zu < %zu bytes", ws_bytes, need);
+    return NQA_E_WORKSPACE;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const size_t ab = act_bytes(n, H, W, prec);
+  char *bufA = static_cast<char *>(ws), *bufB = bufA + ab;
+  double *part = reinterpret_cast<double *>(bufB + ab);
+  const PyrDims d = pyr_dims(H, W);
+  int C[6], HW[6];
+  C[0] = 3;
+  HW[0] = H * W;
+  for (int k = 0; k < 5; ++k) {
+    C[k + 1] = kChns[k + 1];
+    HW[k + 1] = d.h[k] * d.w[k];
+  }
+  const StatsPlan p = stats_plan(B, C, HW, 6, prec, true);
+  int rc;
+  // feature 0 is the raw image (DISTS_pt.py:103): statistics straight from the inputs
+  if ((rc = stats_nchw(x, y, B, 3, H * W, part + p.d.part_off[0], st))) return rc;
+  // x images occupy [0,B), y images [B,2B) of one NHWC batch
+  if ((rc = conv1_1(x, B, H, W, packed, prec, bufA, st))) return rc;
+  if ((rc = conv1_1(y, B, H, W, packed, prec, bufA + (size_t)B * H * W * 64 * prec_elem_bytes(prec), st))) return rc;
+  rc = run_stages(
+      bufA, bufB, n, H, W, packed, prec, nullptr,
+      [&](int k, void *tap, int hk, int wk, int ck) {
+        return stats_nhwc(tap, B, hk * wk, ck, prec, part + p.d.part_off[k + 1], st);
+      },
+      st);
+  if (rc) return rc;
+  return finalize(part, p.d, B, s1, s2, st);
+}
+
+size_t nqa_stats_scratch_bytes(int B, const int C[NQA_NUM_TAPS], const int Hk[NQA_NUM_TAPS],
+                               const int Wk[NQA_NUM_TAPS]) {
+  if (B <= 0 || !C || !Hk || !Wk) return 0;
+  int HW[6];
+  for (int k = 0; k < 6; ++k) HW[k] = Hk[k] * Wk[k];
+  return align_up(stats_plan(B, C, HW, 6, NQA_PREC_F32, false).doubles * 8, 256);
+}
+
+int nqa_dists_stats_nchw(const float *const fx[NQA_NUM_TAPS], const float *const fy[NQA_NUM_TAPS], int B,
+                         const int C[NQA_NUM_TAPS], const int Hk[NQA_NUM_TAPS], const int Wk[NQA_NUM_TAPS],
+                         void *scratch, size_t scratch_bytes, float *s1, float *s2, void *stream) {
+  if (!fx || !fy || !C || !Hk || !Wk || !scratch || !s1 || !s2 || B <= 0) {
+    set_error("dists_stats_nchw: bad argument");
+    return NQA_E_ARG;
+  }
+  int HW[6];
+  for (int k = 0; k < 6; ++k) {
+    if (!fx[k] || !fy[k] || C[k] <= 0 || Hk[k] <= 0 || Wk[k] <= 0) {
+      set_error("dists_stats_nchw: bad feature %d", k);
+      return NQA_E_ARG;
+    }
+    HW[k] = Hk[k] * Wk[k];
+  }
+  const StatsPlan p = stats_plan(B, C, HW, 6, NQA_PREC_F32, false);
+  if (scratch_bytes < p.doubles * 8) {
+    set_error("dists_stats_nchw: scratch %zu < %zu bytes", scratch_bytes, p.doubles * 8);
+    return NQA_E_WORKSPACE;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  double *part = static_cast<double *>(scratch);
+  int rc;
+  for (int k = 0; k < 6; ++k)
+    if ((rc = stats_nchw(fx[k], fy[k], B, C[k], HW[k], part + p.d.part_off[k], st))) return rc;
+  return finalize(part, p.d, B, s1, s2, st);
+}
+
+int nqa_dists_score(const float *s1, const float *s2, const float *alpha, const float *beta, int B, float *out,
+                    void *stream) {
+  if (!s1 || !s2 || !alpha || !beta || !out || B <= 0) {
+    set_error("dists_score: bad argument");
+    return NQA_E_ARG;
+  }
+  return score(s1, s2, alpha, beta, B, out, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

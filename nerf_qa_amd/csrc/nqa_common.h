@@ -1,0 +1,125 @@
+// Shared device/host helpers for libnqa_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/nqa.h"
+
+namespace nqa {
+
+// ---- error plumbing ------------------------------------------------------------
+void set_error(const char *fmt, ...);
+int check_launch(const char *what);
+
+// ---- timing ring (bench.py roofline leg) -----------------------------------------
+struct TimedLaunch {
+  TimedLaunch(int kclass, hipStream_t s);
+  ~TimedLaunch();
+  int kclass;
+  hipStream_t stream;
+  int slot;
+};
+
+// ---- precision traits ------------------------------------------------------------
+// One 16-byte "k-chunk" is the unit every tile is staged and read in: 8 sixteen-bit
+// channels or 4 floats.  A 64-byte pixel record (4 chunks) is one LDS row.
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+struct PrecF32 {
+  typedef float T;
+  static constexpr int ID = NQA_PREC_F32;
+  static constexpr int CPC = 4;   // channels per 16-byte chunk
+  static constexpr int KC = 16;   // channels per 64-byte LDS row
+  __device__ static inline float to_f(T v) { return v; }
+  __device__ static inline T from_f(float v) { return v; }
+  // one chunk pair -> K=8 of the contraction as four exact-f32 MFMAs (K=2 each)
+  __device__ static inline f32x16 mma(u32x4 a, u32x4 b, f32x16 c) {
+    f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0], bf[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1], bf[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[2], bf[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[3], bf[3], c, 0, 0, 0);
+    return c;
+  }
+};
+struct PrecBF16 {
+  typedef __bf16 T;
+  static constexpr int ID = NQA_PREC_BF16;
+  static constexpr int CPC = 8;
+  static constexpr int KC = 32;
+  __device__ static inline float to_f(T v) { return (float)v; }
+  __device__ static inline T from_f(float v) { return (T)v; }
+  __device__ static inline f32x16 mma(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0,
+                                                   0, 0);
+  }
+};
+struct PrecF16 {
+  typedef _Float16 T;
+  static constexpr int ID = NQA_PREC_F16;
+  static constexpr int CPC = 8;
+  static constexpr int KC = 32;
+  __device__ static inline float to_f(T v) { return (float)v; }
+  __device__ static inline T from_f(float v) { return (T)v; }
+  __device__ static inline f32x16 mma(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0,
+                                                  0);
+  }
+};
+
+__host__ __device__ static inline size_t prec_elem_bytes(int prec) { return prec == NQA_PREC_F32 ? 4 : 2; }
+
+// ---- VGG plan --------------------------------------------------------------------
+struct ConvSpec {
+  int cin, cout, stage;  // stage 0..4 (after which tap k=stage+1 is taken when last==1)
+  int last;
+};
+static const ConvSpec kConvs[NQA_NUM_CONVS] = {
+    {3, 64, 0, 0},    {64, 64, 0, 1},   {64, 128, 1, 0},  {128, 128, 1, 1}, {128, 256, 2, 0},
+    {256, 256, 2, 0}, {256, 256, 2, 1}, {256, 512, 3, 0}, {512, 512, 3, 0}, {512, 512, 3, 1},
+    {512, 512, 4, 0}, {512, 512, 4, 0}, {512, 512, 4, 1}};
+static const int kChns[NQA_NUM_TAPS] = {3, 64, 128, 256, 512, 512};
+static const int kChnOff[NQA_NUM_TAPS] = {0, 3, 67, 195, 451, 963};
+
+// Cout tile of the implicit-GEMM kernel for a layer.
+static inline int conv_bn(int cout) { return cout >= 128 ? 128 : 64; }
+
+// Packed-blob offsets (bytes).  Layer 0: float w[27][64] (k = (ky*3+kx)*3+c) then float
+// bias[64].  Layers 1..12: tiles [cout/BN][cin/KC][9][BN] rows of 64 bytes (chunk c of
+// row n stored at position c ^ ((n>>2)&3)), then float bias[cout].
+size_t layer_offset(int layer, int prec);
+size_t layer_bias_offset(int layer, int prec);
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Where each stage's partial sums live and how to fold them (finalize_kernel).
+struct StageDesc {
+  long part_off[NQA_NUM_TAPS];  // offset (in doubles) of each stage's partial block
+  int nblk[NQA_NUM_TAPS];
+  int hw[NQA_NUM_TAPS];
+  int c[NQA_NUM_TAPS];
+  int coff[NQA_NUM_TAPS];  // channel offset of the stage inside the concatenated vector
+  int nstage;
+  int ctot;
+};
+
+// ---- host launchers shared between translation units ---------------------------------
+int conv1_1(const float *x, int n, int H, int W, const void *packed, int prec, void *out, hipStream_t st);
+int conv3x3(const void *in, int n, int H, int W, int layer, const void *packed, int prec, void *out, hipStream_t st);
+int l2pool(const void *in, int n, int H, int W, int C, int prec, void *out, hipStream_t st);
+int stats_nhwc_ppb(int C, int prec);
+int stats_nchw_ppb(int HW);
+int stats_nhwc(const void *feat, int B, int HW, int C, int prec, double *part, hipStream_t st);
+int stats_nchw(const float *fx, const float *fy, int B, int C, int HW, double *part, hipStream_t st);
+int finalize(const double *part, const StageDesc &d, int B, float *s1, float *s2, hipStream_t st);
+int score(const float *s1, const float *s2, const float *alpha, const float *beta, int B, float *out, hipStream_t st);
+int nhwc_to_nchw(const void *in, int n, int HW, int C, int prec, float *out, hipStream_t st);
+
+}  // namespace nqa

@@ -1,0 +1,309 @@
+// HBM-bound kernels of the DISTS path for gfx950: L2-pool, per-channel statistics,
+// similarity finalisation, alpha/beta score, and the NHWC -> NCHW export.
+//
+//   l2pool_kernel        L2pooling.forward, nerf_qa/DISTS_pytorch/DISTS_pt.py:22-25
+//   stats_nhwc_kernel    the five sums behind DISTS_pt.py:131-139 on 16-byte channel groups
+//   stats_nchw_kernel    same sums on float32 NCHW planes (stage 0 = raw image, and the
+//                        forward_from_feats entry, DISTS_pt.py:181-202)
+//   finalize_kernel      mean / variance / covariance -> S1, S2 (DISTS_pt.py:134,141)
+//   score_kernel         alpha/beta weighted sum -> 1 - (dist1+dist2) (DISTS_pt.py:127-144)
+//
+// Statistics are accumulated in float64 end to end.  The reference takes the variance
+// by a second pass over (f - mean); one pass over sum(f^2) in fp32 would lose digits at
+// 2 M pixels, while fp64 sums of exactly-representable fp32 products keep ~16 digits and
+// let every feature byte be read once.  FP64 FMA is cheap next to the HBM stream here.
+#include "nqa_common.h"
+
+namespace nqa {
+
+// ---------------------------------------------------------------------------------
+template <typename P>
+__global__ __launch_bounds__(256) void l2pool_kernel(const typename P::T *__restrict__ in,
+                                                     typename P::T *__restrict__ out, int H, int W, int C, int Ho,
+                                                     int Wo, long total) {
+  typedef typename P::T T;
+  typedef __attribute__((ext_vector_type(P::CPC))) T tvec;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int G = C / P::CPC;
+  const int g = (int)(idx % G);
+  long t = idx / G;
+  const int ox = (int)(t % Wo);
+  t /= Wo;
+  const int oy = (int)(t % Ho);
+  const int n = (int)(t / Ho);
+  float acc[P::CPC];
+#pragma unroll
+  for (int e = 0; e < P::CPC; ++e) acc[e] = 0.f;
+  const T *base = in + (size_t)n * H * W * C + g * P::CPC;
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy) {
+    const int iy = 2 * oy - 1 + dy;
+    if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int ix = 2 * ox - 1 + dx;
+      if ((unsigned)ix >= (unsigned)W) continue;
+      const float wgt = ((dy == 1) ? 0.5f : 0.25f) * ((dx == 1) ? 0.5f : 0.25f);
+      const tvec v = *reinterpret_cast<const tvec *>(base + ((size_t)iy * W + ix) * C);
+#pragma unroll
+      for (int e = 0; e < P::CPC; ++e) {
+        const float f = P::to_f(v[e]);
+        acc[e] = fmaf(f * f, wgt, acc[e]);
+      }
+    }
+  }
+  tvec o;
+#pragma unroll
+  for (int e = 0; e < P::CPC; ++e) o[e] = P::from_f(sqrtf(acc[e] + 1e-12f));
+  *reinterpret_cast<tvec *>(out + (((size_t)n * Ho + oy) * Wo + ox) * C + g * P::CPC) = o;
+}
+
+// ---------------------------------------------------------------------------------
+// Partial sums layout: part[((b*nblk + blk)*C + c)*5 + s], s = {sum x, sum y, sum x^2, sum y^2, sum xy}.
+template <typename P>
+__global__ __launch_bounds__(256) void stats_nhwc_kernel(const typename P::T *__restrict__ feat, int B, int HW, int C,
+                                                         int pix_per_block, double *__restrict__ part) {
+  typedef typename P::T T;
+  typedef __attribute__((ext_vector_type(P::CPC))) T tvec;
+  __shared__ double red[256 * P::CPC];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
+  const int G = C / P::CPC;   // 16-byte channel groups per pixel (<= 128)
+  const int PL = 256 / G;     // pixels handled side by side
+  const int g = tid % G, pl = tid / G;
+  const int p_begin = blk * pix_per_block;
+  const int p_end = min(HW, p_begin + pix_per_block);
+  double acc[P::CPC][5];
+#pragma unroll
+  for (int e = 0; e < P::CPC; ++e)
+#pragma unroll
+    for (int s = 0; s < 5; ++s) acc[e][s] = 0.0;
+  const T *fx = feat + (size_t)b * HW * C + g * P::CPC;
+  const T *fy = feat + (size_t)(B + b) * HW * C + g * P::CPC;
+  if (pl < PL) {
+#pragma unroll 2
+    for (int p = p_begin + pl; p < p_end; p += PL) {
+      const tvec vx = *reinterpret_cast<const tvec *>(fx + (size_t)p * C);
+      const tvec vy = *reinterpret_cast<const tvec *>(fy + (size_t)p * C);
+#pragma unroll
+      for (int e = 0; e < P::CPC; ++e) {
+        const double x = (double)P::to_f(vx[e]), y = (double)P::to_f(vy[e]);
+        acc[e][0] += x;
+        acc[e][1] += y;
+        acc[e][2] = fma(x, x, acc[e][2]);
+        acc[e][3] = fma(y, y, acc[e][3]);
+        acc[e][4] = fma(x, y, acc[e][4]);
+      }
+    }
+  }
+  double *dst = part + ((size_t)b * nblk + blk) * C * 5;
+#pragma unroll
+  for (int s = 0; s < 5; ++s) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < P::CPC; ++e) red[tid * P::CPC + e] = acc[e][s];
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+      const int cg = c / P::CPC, ce = c % P::CPC;
+      double sum = 0.0;
+      for (int q = 0; q < PL; ++q) sum += red[(q * G + cg) * P::CPC + ce];
+      dst[(size_t)c * 5 + s] = sum;
+    }
+  }
+}
+
+// float32 NCHW planes: grid (B*C, nblk).  fx, fy: (B, C, HW).
+__global__ __launch_bounds__(256) void stats_nchw_kernel(const float *__restrict__ fx, const float *__restrict__ fy,
+                                                         int C, int HW, int pix_per_block, double *__restrict__ part) {
+  __shared__ double red[5][256];
+  const int tid = threadIdx.x;
+  const int bc = blockIdx.x, blk = blockIdx.y, nblk = gridDim.y;
+  const int b = bc / C, c = bc - b * C;
+  const float *px = fx + (size_t)bc * HW, *py = fy + (size_t)bc * HW;
+  const int p_begin = blk * pix_per_block;
+  const int p_end = min(HW, p_begin + pix_per_block);
+  double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+#pragma unroll 4
+  for (int p = p_begin + tid; p < p_end; p += 256) {
+    const double x = (double)px[p], y = (double)py[p];
+    a0 += x;
+    a1 += y;
+    a2 = fma(x, x, a2);
+    a3 = fma(y, y, a3);
+    a4 = fma(x, y, a4);
+  }
+  red[0][tid] = a0;
+  red[1][tid] = a1;
+  red[2][tid] = a2;
+  red[3][tid] = a3;
+  red[4][tid] = a4;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (tid < off) {
+#pragma unroll
+      for (int s = 0; s < 5; ++s) red[s][tid] += red[s][tid + off];
+    }
+    __syncthreads();
+  }
+  if (tid < 5) part[(((size_t)b * nblk + blk) * C + c) * 5 + tid] = red[tid][0];
+}
+
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void finalize_kernel(const double *__restrict__ part, StageDesc d,
+                                                       float *__restrict__ s1, float *__restrict__ s2) {
+  const int b = blockIdx.y;
+  const int gc = blockIdx.x * 256 + threadIdx.x;
+  if (gc >= d.ctot) return;
+  int k = 0;
+  while (k + 1 < d.nstage && gc >= d.coff[k + 1]) ++k;
+  const int c = gc - d.coff[k];
+  const double *p = part + d.part_off[k] + ((size_t)b * d.nblk[k] * d.c[k] + c) * 5;
+  double s[5] = {0, 0, 0, 0, 0};
+  for (int blk = 0; blk < d.nblk[k]; ++blk) {
+#pragma unroll
+    for (int q = 0; q < 5; ++q) s[q] += p[(size_t)blk * d.c[k] * 5 + q];
+  }
+  const double inv = 1.0 / (double)d.hw[k];
+  const double mx = s[0] * inv, my = s[1] * inv;
+  const double vx = s[2] * inv - mx * mx, vy = s[3] * inv - my * my;
+  const double cov = s[4] * inv - mx * my;
+  const double c1 = 1e-6, c2 = 1e-6;
+  s1[(size_t)b * d.ctot + gc] = (float)((2.0 * mx * my + c1) / (mx * mx + my * my + c1));
+  s2[(size_t)b * d.ctot + gc] = (float)((2.0 * cov + c2) / (vx + vy + c2));
+}
+
+// one block per pair: score_b = 1 - sum_c (alpha_c*S1 + beta_c*S2)/w
+__global__ __launch_bounds__(256) void score_kernel(const float *__restrict__ s1, const float *__restrict__ s2,
+                                                    const float *__restrict__ alpha, const float *__restrict__ beta,
+                                                    int ctot, float *__restrict__ score) {
+  __shared__ double red[2][256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  double w = 0.0, d = 0.0;
+  for (int c = tid; c < ctot; c += 256) {
+    const double a = alpha[c], be = beta[c];
+    w += a + be;
+    d += a * (double)s1[(size_t)b * ctot + c] + be * (double)s2[(size_t)b * ctot + c];
+  }
+  red[0][tid] = w;
+  red[1][tid] = d;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (tid < off) {
+      red[0][tid] += red[0][tid + off];
+      red[1][tid] += red[1][tid + off];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) score[b] = (float)(1.0 - red[1][0] / red[0][0]);
+}
+
+// ---------------------------------------------------------------------------------
+// NHWC (T) -> NCHW float32 through a 64-pixel x 64-channel LDS tile.
+template <typename P>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const typename P::T *__restrict__ in,
+                                                           float *__restrict__ out, int HW, int C) {
+  __shared__ float tile[64][65];
+  const int n = blockIdx.z;
+  const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) {
+    const int p = p0 + r, c = c0 + tx;
+    tile[r][tx] = (p < HW && c < C) ? P::to_f(in[((size_t)n * HW + p) * C + c]) : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4) {
+    const int c = c0 + r, p = p0 + tx;
+    if (p < HW && c < C) out[((size_t)n * C + c) * HW + p] = tile[tx][r];
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// host launchers
+// ---------------------------------------------------------------------------------
+template <typename P>
+static int launch_l2pool(const void *in, int n, int H, int W, int C, void *out, hipStream_t st) {
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const long total = (long)n * Ho * Wo * (C / P::CPC);
+  TimedLaunch t(NQA_K_POOL, st);
+  l2pool_kernel<P><<<dim3((unsigned)((total + 255) / 256)), 256, 0, st>>>(
+      reinterpret_cast<const typename P::T *>(in), reinterpret_cast<typename P::T *>(out), H, W, C, Ho, Wo, total);
+  return check_launch("l2pool");
+}
+
+int l2pool(const void *in, int n, int H, int W, int C, int prec, void *out, hipStream_t st) {
+  switch (prec) {
+    case NQA_PREC_F32: return launch_l2pool<PrecF32>(in, n, H, W, C, out, st);
+    case NQA_PREC_BF16: return launch_l2pool<PrecBF16>(in, n, H, W, C, out, st);
+    case NQA_PREC_F16: return launch_l2pool<PrecF16>(in, n, H, W, C, out, st);
+  }
+  set_error("l2pool: unknown prec %d", prec);
+  return NQA_E_ARG;
+}
+
+// pixels per block for the NHWC statistics kernel: 64 pixels per thread column.
+int stats_nhwc_ppb(int C, int prec) {
+  const int cpc = prec == NQA_PREC_F32 ? 4 : 8;
+  const int PL = 256 / (C / cpc);
+  return 64 * PL;
+}
+int stats_nchw_ppb(int HW) { return HW > 65536 ? 65536 : (HW > 0 ? HW : 1); }
+
+template <typename P>
+static int launch_stats_nhwc(const void *feat, int B, int HW, int C, double *part, hipStream_t st) {
+  const int ppb = stats_nhwc_ppb(C, P::ID);
+  dim3 grid(cdiv(HW, ppb), B);
+  TimedLaunch t(NQA_K_STATS, st);
+  stats_nhwc_kernel<P><<<grid, 256, 0, st>>>(reinterpret_cast<const typename P::T *>(feat), B, HW, C, ppb, part);
+  return check_launch("stats_nhwc");
+}
+
+int stats_nhwc(const void *feat, int B, int HW, int C, int prec, double *part, hipStream_t st) {
+  switch (prec) {
+    case NQA_PREC_F32: return launch_stats_nhwc<PrecF32>(feat, B, HW, C, part, st);
+    case NQA_PREC_BF16: return launch_stats_nhwc<PrecBF16>(feat, B, HW, C, part, st);
+    case NQA_PREC_F16: return launch_stats_nhwc<PrecF16>(feat, B, HW, C, part, st);
+  }
+  set_error("stats: unknown prec %d", prec);
+  return NQA_E_ARG;
+}
+
+int stats_nchw(const float *fx, const float *fy, int B, int C, int HW, double *part, hipStream_t st) {
+  const int ppb = stats_nchw_ppb(HW);
+  dim3 grid(B * C, cdiv(HW, ppb));
+  TimedLaunch t(NQA_K_STATS, st);
+  stats_nchw_kernel<<<grid, 256, 0, st>>>(fx, fy, C, HW, ppb, part);
+  return check_launch("stats_nchw");
+}
+
+int finalize(const double *part, const StageDesc &d, int B, float *s1, float *s2, hipStream_t st) {
+  dim3 grid(cdiv(d.ctot, 256), B);
+  TimedLaunch t(NQA_K_STATS, st);
+  finalize_kernel<<<grid, 256, 0, st>>>(part, d, s1, s2);
+  return check_launch("finalize");
+}
+
+int score(const float *s1, const float *s2, const float *alpha, const float *beta, int B, float *out,
+          hipStream_t st) {
+  score_kernel<<<B, 256, 0, st>>>(s1, s2, alpha, beta, NQA_TOTAL_CHNS, out);
+  return check_launch("score");
+}
+
+template <typename P>
+static int launch_export(const void *in, int n, int HW, int C, float *out, hipStream_t st) {
+  dim3 grid(cdiv(HW, 64), cdiv(C, 64), n);
+  nhwc_to_nchw_kernel<P><<<grid, 256, 0, st>>>(reinterpret_cast<const typename P::T *>(in), out, HW, C);
+  return check_launch("nhwc_to_nchw");
+}
+
+int nhwc_to_nchw(const void *in, int n, int HW, int C, int prec, float *out, hipStream_t st) {
+  switch (prec) {
+    case NQA_PREC_F32: return launch_export<PrecF32>(in, n, HW, C, out, st);
+    case NQA_PREC_BF16: return launch_export<PrecBF16>(in, n, HW, C, out, st);
+    case NQA_PREC_F16: return launch_export<PrecF16>(in, n, HW, C, out, st);
+  }
+  set_error("nhwc_to_nchw: unknown prec %d", prec);
+  return NQA_E_ARG;
+}
+
+}  // namespace nqa

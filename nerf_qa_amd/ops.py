@@ -1,0 +1,203 @@
+"""Tensor-level wrappers over the C ABI (include/nqa.h).
+
+PyTorch is plumbing here: it owns device memory and the current HIP stream; every
+number is produced by the kernels in libnqa_hip.so.  All functions require CUDA (ROCm)
+tensors and raise otherwise -- there is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import NUM_CONVS, PREC_DTYPE, TOTAL_CHNS, check, lib, prec_id, ptr, stream_ptr
+
+CHNS = (3, 64, 128, 256, 512, 512)
+CONV_COUT = (64, 64, 128, 128, 256, 256, 256, 512, 512, 512, 512, 512, 512)
+CONV_CIN = (3, 64, 64, 128, 128, 256, 256, 256, 512, 512, 512, 512, 512)
+CONV_STAGE = (0, 0, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 4)
+
+
+def _need_cuda(*ts: torch.Tensor) -> torch.device:
+    dev = ts[0].device
+    for t in ts:
+        if not t.is_cuda:
+            raise _lib.NqaError("nerf_qa_amd runs on the GPU only: got a tensor on %s "
+                                "(move inputs and the module to cuda; there is no CPU fallback)" % t.device)
+        if t.device != dev:
+            raise _lib.NqaError("tensors on different devices")
+    return dev
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def pyramid_dims(h: int, w: int):
+    dims = [(h, w)]
+    for _ in range(4):
+        h, w = (h + 1) // 2, (w + 1) // 2
+        dims.append((h, w))
+    return dims
+
+
+def pack_vgg_weights(convs: Sequence, prec) -> torch.Tensor:
+    """13 (weight OIHW, bias) pairs (numpy or torch, any device) -> packed blob (CPU uint8 tensor)."""
+    p = prec_id(prec)
+    if len(convs) != NUM_CONVS:
+        raise ValueError("expected 13 conv layers")
+    ws, bs = [], []
+    for li, (w, b) in enumerate(convs):
+        w = np.ascontiguousarray(w.detach().cpu().numpy() if torch.is_tensor(w) else w, dtype=np.float32)
+        b = np.ascontiguousarray(b.detach().cpu().numpy() if torch.is_tensor(b) else b, dtype=np.float32)
+        if w.shape != (CONV_COUT[li], CONV_CIN[li], 3, 3) or b.shape != (CONV_COUT[li],):
+            raise ValueError(f"conv {li}: unexpected shape {w.shape} / {b.shape}")
+        ws.append(w)
+        bs.append(b)
+    nbytes = lib().nqa_packed_weights_bytes(p)
+    blob = torch.empty(nbytes, dtype=torch.uint8)
+    wp = (C.c_void_p * NUM_CONVS)(*[w.ctypes.data for w in ws])
+    bp = (C.c_void_p * NUM_CONVS)(*[b.ctypes.data for b in bs])
+    check(lib().nqa_pack_vgg_weights(wp, bp, p, blob.data_ptr()))
+    return blob
+
+
+def conv1_1(x: torch.Tensor, packed: torch.Tensor, prec) -> torch.Tensor:
+    p = prec_id(prec)
+    dev = _need_cuda(x, packed)
+    x = _f32c(x)
+    n, c, h, w = x.shape
+    assert c == 3
+    out = torch.empty((n, h, w, 64), dtype=PREC_DTYPE[p], device=dev)
+    check(lib().nqa_conv1_1(ptr(x), n, h, w, ptr(packed), p, ptr(out), stream_ptr(dev)))
+    return out
+
+
+def conv3x3_relu(inp: torch.Tensor, layer: int, packed: torch.Tensor, prec) -> torch.Tensor:
+    p = prec_id(prec)
+    dev = _need_cuda(inp, packed)
+    assert inp.dtype == PREC_DTYPE[p] and inp.is_contiguous()
+    n, h, w, c = inp.shape
+    assert c == CONV_CIN[layer]
+    out = torch.empty((n, h, w, CONV_COUT[layer]), dtype=inp.dtype, device=dev)
+    check(lib().nqa_conv3x3_relu(ptr(inp), n, h, w, layer, ptr(packed), p, ptr(out), stream_ptr(dev)))
+    return out
+
+
+def l2pool(inp: torch.Tensor, prec) -> torch.Tensor:
+    p = prec_id(prec)
+    dev = _need_cuda(inp)
+    assert inp.dtype == PREC_DTYPE[p] and inp.is_contiguous()
+    n, h, w, c = inp.shape
+    out = torch.empty((n, (h + 1) // 2, (w + 1) // 2, c), dtype=inp.dtype, device=dev)
+    check(lib().nqa_l2pool(ptr(inp), n, h, w, c, p, ptr(out), stream_ptr(dev)))
+    return out
+
+
+def nhwc_to_nchw_f32(inp: torch.Tensor, prec) -> torch.Tensor:
+    p = prec_id(prec)
+    dev = _need_cuda(inp)
+    assert inp.dtype == PREC_DTYPE[p] and inp.is_contiguous()
+    n, h, w, c = inp.shape
+    out = torch.empty((n, c, h, w), dtype=torch.float32, device=dev)
+    check(lib().nqa_nhwc_to_nchw_f32(ptr(inp), n, h, w, c, p, ptr(out), stream_ptr(dev)))
+    return out
+
+
+class Workspace:
+    """Grow-only device scratch, one per (module, device); avoids allocator traffic per call."""
+
+    def __init__(self):
+        self.buf = None
+
+    def get(self, nbytes: int, dev: torch.device) -> torch.Tensor:
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != dev:
+            self.buf = None
+            self.buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
+        return self.buf
+
+
+def vgg_pyramid(x: torch.Tensor, packed: torch.Tensor, prec, ws: Workspace | None = None) -> List[torch.Tensor]:
+    """Five tapped maps relu1_2..relu5_3 as NHWC tensors in prec's dtype."""
+    p = prec_id(prec)
+    dev = _need_cuda(x, packed)
+    x = _f32c(x)
+    n, c, h, w = x.shape
+    assert c == 3
+    taps = [torch.empty((n, hk, wk, ck), dtype=PREC_DTYPE[p], device=dev)
+            for (hk, wk), ck in zip(pyramid_dims(h, w), CHNS[1:])]
+    nbytes = lib().nqa_workspace_bytes(n, h, w, p)
+    buf = (ws or Workspace()).get(nbytes, dev)
+    tp = (C.c_void_p * 5)(*[ptr(t) for t in taps])
+    check(lib().nqa_vgg_pyramid(ptr(x), n, h, w, ptr(packed), p, ptr(buf), buf.numel(), tp, stream_ptr(dev)))
+    return taps
+
+
+def dists_forward(x: torch.Tensor, y: torch.Tensor, packed: torch.Tensor, prec, ws: Workspace | None = None):
+    """(S1, S2), each float32 (B, 1475): both pyramids + statistics in one enqueue."""
+    p = prec_id(prec)
+    dev = _need_cuda(x, y, packed)
+    x, y = _f32c(x), _f32c(y)
+    if x.shape != y.shape or x.dim() != 4 or x.shape[1] != 3:
+        raise ValueError(f"expected two (B,3,H,W) tensors of equal shape, got {tuple(x.shape)} / {tuple(y.shape)}")
+    b, _, h, w = x.shape
+    s1 = torch.empty((b, TOTAL_CHNS), dtype=torch.float32, device=dev)
+    s2 = torch.empty((b, TOTAL_CHNS), dtype=torch.float32, device=dev)
+    nbytes = lib().nqa_workspace_bytes(2 * b, h, w, p)
+    buf = (ws or Workspace()).get(nbytes, dev)
+    check(lib().nqa_dists_forward(ptr(x), ptr(y), b, h, w, ptr(packed), p, ptr(buf), buf.numel(), ptr(s1), ptr(s2),
+                                  stream_ptr(dev)))
+    return s1, s2
+
+
+def dists_stats_nchw(feats0: Sequence[torch.Tensor], feats1: Sequence[torch.Tensor]):
+    """(S1, S2) from two lists of six float32 NCHW feature maps (forward_from_feats)."""
+    if len(feats0) != 6 or len(feats1) != 6:
+        raise ValueError("expected six feature maps per image")
+    dev = _need_cuda(*feats0, *feats1)
+    f0 = [_f32c(f) for f in feats0]
+    f1 = [_f32c(f) for f in feats1]
+    b = f0[0].shape[0]
+    for a, c in zip(f0, f1):
+        if a.shape != c.shape or a.dim() != 4 or a.shape[0] != b:
+            raise ValueError("feature lists disagree in shape")
+    cs = (C.c_int * 6)(*[f.shape[1] for f in f0])
+    hs = (C.c_int * 6)(*[f.shape[2] for f in f0])
+    wsz = (C.c_int * 6)(*[f.shape[3] for f in f0])
+    ctot = sum(f.shape[1] for f in f0)
+    s1 = torch.empty((b, ctot), dtype=torch.float32, device=dev)
+    s2 = torch.empty((b, ctot), dtype=torch.float32, device=dev)
+    nbytes = lib().nqa_stats_scratch_bytes(b, cs, hs, wsz)
+    scratch = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
+    p0 = (C.c_void_p * 6)(*[ptr(f) for f in f0])
+    p1 = (C.c_void_p * 6)(*[ptr(f) for f in f1])
+    check(lib().nqa_dists_stats_nchw(p0, p1, b, cs, hs, wsz, ptr(scratch), scratch.numel(), ptr(s1), ptr(s2),
+                                     stream_ptr(dev)))
+    return s1, s2
+
+
+def dists_score(s1: torch.Tensor, s2: torch.Tensor, alpha: torch.Tensor, beta: torch.Tensor) -> torch.Tensor:
+    """score (B,) = 1 - sum(alpha*S1 + beta*S2)/(sum alpha + sum beta), fused kernel (no autograd)."""
+    dev = _need_cuda(s1, s2, alpha, beta)
+    s1, s2 = _f32c(s1), _f32c(s2)
+    a, b_ = _f32c(alpha.detach().reshape(-1)), _f32c(beta.detach().reshape(-1))
+    assert s1.shape == s2.shape and s1.shape[1] == TOTAL_CHNS == a.numel() == b_.numel()
+    out = torch.empty((s1.shape[0],), dtype=torch.float32, device=dev)
+    check(lib().nqa_dists_score(ptr(s1), ptr(s2), ptr(a), ptr(b_), s1.shape[0], ptr(out), stream_ptr(dev)))
+    return out
+
+
+def timing_enable(on: bool) -> None:
+    check(lib().nqa_timing_enable(1 if on else 0))
+
+
+def timing_collect():
+    n = (C.c_int * 5)()
+    ms = (C.c_double * 5)()
+    check(lib().nqa_timing_collect(n, ms))
+    return {name: (n[i], ms[i]) for i, name in enumerate(_lib.K_NAMES)}

@@ -1,0 +1,35 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def np_convs():
+    from nerf_qa_amd import synth
+    return synth.vgg16_weights(1234)
+
+
+@pytest.fixture(scope="session")
+def oracle_convs(np_convs):
+    from oracle import dists_oracle
+    return dists_oracle.convs_from_numpy(np_convs)
+
+
+@pytest.fixture(scope="session")
+def alpha_beta():
+    import numpy as np
+    import torch
+    d = np.load(os.path.join(ROOT, "nerf_qa_amd", "data", "dists_alpha_beta.npz"))
+    return torch.from_numpy(d["alpha"]).view(1, -1, 1, 1), torch.from_numpy(d["beta"]).view(1, -1, 1, 1)
+
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")

@@ -1,0 +1,88 @@
+"""CPU-side checks: the C-ABI library loads, exports every declared symbol, validates
+arguments, and its host-side weight packer lays tiles out as the kernels expect."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from nerf_qa_amd import build, _lib
+    build.build()
+    return _lib.lib()
+
+
+def test_exports_match_header(lib):
+    from nerf_qa_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "nqa.h")).read()
+    declared = set(re.findall(r"\b(nqa_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name)
+
+
+def test_argument_errors(lib):
+    assert lib.nqa_conv1_1(None, 1, 8, 8, None, 0, None, None) == -1
+    assert b"null" in lib.nqa_last_error()
+    assert lib.nqa_packed_weights_bytes(0) > lib.nqa_packed_weights_bytes(1) == lib.nqa_packed_weights_bytes(2)
+    assert lib.nqa_workspace_bytes(0, 8, 8, 0) == 0
+
+
+def _unpack_layer(blob, off, cin, cout, dtype, cpc):
+    """Invert the documented tile layout back to OIHW (numpy)."""
+    kc, bn = 4 * cpc, (128 if cout >= 128 else 64)
+    ncc = cin // kc
+    n_el = cin * cout * 9
+    raw = blob[off:off + n_el * dtype().itemsize].view(dtype).reshape(cout // bn, ncc, 9, bn, 4, cpc)
+    w = np.zeros((cout, cin, 9), dtype=dtype)
+    for n in range(bn):
+        for pos in range(4):
+            c = pos ^ ((n >> 2) & 3)
+            # raw[ct, cc, t, n, pos, j] -> w[ct*bn+n, cc*kc + c*cpc + j, t]
+            src = raw[:, :, :, n, pos, :]  # (ct, cc, t, j)
+            for ct in range(cout // bn):
+                for cc in range(ncc):
+                    w[ct * bn + n, cc * kc + c * cpc:cc * kc + (c + 1) * cpc, :] = src[ct, cc].T
+    return w.reshape(cout, cin, 3, 3)
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16", "f16"])
+def test_pack_roundtrip(prec, np_convs, lib):
+    from nerf_qa_amd import ops
+    blob = ops.pack_vgg_weights(np_convs, prec).numpy()
+    # recompute the documented offsets
+    esz = 4 if prec == "f32" else 2
+    al = lambda v: (v + 255) // 256 * 256
+    off = al(27 * 64 * 4 + 64 * 4)
+    w0 = blob[:27 * 64 * 4].view(np.float32).reshape(9, 3, 64)
+    assert np.array_equal(w0, np_convs[0][0].reshape(64, 3, 9).transpose(2, 1, 0))
+    for l in (1, 2, 7, 12):
+        cin, cout = ops.CONV_CIN[l], ops.CONV_COUT[l]
+        o = off + sum(al(ops.CONV_CIN[i] * ops.CONV_COUT[i] * 9 * esz) + al(ops.CONV_COUT[i] * 4) for i in range(1, l))
+        w = np_convs[l][0]
+        if prec == "f32":
+            got = _unpack_layer(blob, o, cin, cout, np.float32, 4)
+            assert np.array_equal(got, w)
+        elif prec == "f16":
+            got = _unpack_layer(blob, o, cin, cout, np.float16, 8)
+            assert np.array_equal(got, w.astype(np.float16))
+        else:
+            got = _unpack_layer(blob, o, cin, cout, np.uint16, 8)
+            ref = torch.from_numpy(w).to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)
+            assert np.array_equal(got, ref)
+        bias = blob[o + al(cin * cout * 9 * esz):][:cout * 4].view(np.float32)
+        assert np.array_equal(bias, np_convs[l][1])
+
+
+def test_no_cpu_fallback():
+    """CPU tensors must be refused, not silently computed somewhere else."""
+    from nerf_qa_amd import _lib, ops
+    x = torch.zeros(1, 3, 8, 8)
+    with pytest.raises(_lib.NqaError):
+        ops.dists_forward(x, x, torch.zeros(16, dtype=torch.uint8), "f32")

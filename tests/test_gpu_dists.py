@@ -1,0 +1,96 @@
+"""End-to-end parity of the HIP DISTS path against the oracle and the golden vectors.
+
+The bar (BASELINE.json north_star): |score_hip - score_ref| <= 1e-4 on identical fp32
+frame pairs.  Because the stand-in weights compress the score range, S1/S2 are gated too.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+SCORE_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def packed(np_convs, dev):
+    from nerf_qa_amd import ops
+    return {p: ops.pack_vgg_weights(np_convs, p).to(dev) for p in ("f32", "f16", "bf16")}
+
+
+def _load_case(path):
+    from nerf_qa_amd import synth
+    g = np.load(path)
+    x, y = synth.frame_batch([int(s) for s in g["seeds"]], int(g["h"]), int(g["w"]), [str(k) for k in g["kinds"]])
+    return g, torch.from_numpy(x), torch.from_numpy(y)
+
+
+DISTS_GOLD = sorted(glob.glob(os.path.join(GOLDEN, "dists_*.npz")))
+
+
+@pytest.mark.parametrize("prec,s_tol", [("f32", 2e-4), ("f16", 5e-3), ("bf16", 4e-2)])
+@pytest.mark.parametrize("path", DISTS_GOLD, ids=[os.path.basename(p)[:-4] for p in DISTS_GOLD])
+def test_dists_vs_golden(path, prec, s_tol, packed, alpha_beta, dev):
+    from nerf_qa_amd import ops
+    g, x, y = _load_case(path)
+    s1, s2 = ops.dists_forward(x.to(dev), y.to(dev), packed[prec], prec)
+    alpha, beta = alpha_beta
+    score = ops.dists_score(s1, s2, alpha.to(dev), beta.to(dev)).cpu().numpy()
+    d = np.abs(score - g["score"]).max()
+    e1 = np.abs(s1.cpu().numpy() - g["s1"]).max()
+    e2 = np.abs(s2.cpu().numpy() - g["s2"]).max()
+    print(f"\n{os.path.basename(path)} [{prec}] |dscore|={d:.2e} |dS1|={e1:.2e} |dS2|={e2:.2e}")
+    assert d <= SCORE_TOL, f"|dscore| {d:.3e} > {SCORE_TOL}"
+    assert e1 <= s_tol and e2 <= s_tol
+
+
+@pytest.mark.parametrize("prec,rtol", [("f32", 3e-5), ("f16", 4e-3), ("bf16", 3e-2)])
+def test_pyramid_taps(prec, rtol, packed, oracle_convs, dev):
+    """forward_once: every tapped map against the oracle, odd size so every stage is ragged."""
+    from nerf_qa_amd import ops, synth
+    from oracle import dists_oracle
+    x, _ = synth.frame_batch([5, 6], 97, 131)
+    x = torch.from_numpy(x)
+    ref = dists_oracle.vgg_pyramid(x, oracle_convs)[1:]
+    taps = ops.vgg_pyramid(x.to(dev), packed[prec], prec)
+    for k, (t, r) in enumerate(zip(taps, ref)):
+        got = ops.nhwc_to_nchw_f32(t, prec).cpu()
+        assert got.shape == r.shape
+        err = (got - r).abs().max().item() / r.abs().max().item()
+        print(f"\n tap {k + 1} [{prec}] rel err {err:.2e}")
+        assert err <= rtol
+
+
+def test_identical_inputs_score_zero(packed, alpha_beta, dev):
+    from nerf_qa_amd import ops, synth
+    x, _ = synth.frame_batch([9], 64, 80)
+    x = torch.from_numpy(x).to(dev)
+    for prec in ("f32", "f16", "bf16"):
+        s1, s2 = ops.dists_forward(x, x.clone(), packed[prec], prec)
+        alpha, beta = alpha_beta
+        score = ops.dists_score(s1, s2, alpha.to(dev), beta.to(dev))
+        assert abs(score.item()) < 2e-6
+
+
+def test_symmetry_and_batch_independence(packed, alpha_beta, dev):
+    """score(x,y)==score(y,x); a pair's score does not depend on its batch neighbours."""
+    from nerf_qa_amd import ops, synth
+    x, y = synth.frame_batch([1, 2, 3], 48, 64)
+    x, y = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
+    alpha, beta = [t.to(dev) for t in alpha_beta]
+    for prec in ("f32", "bf16"):
+        a = ops.dists_score(*ops.dists_forward(x, y, packed[prec], prec), alpha, beta)
+        b = ops.dists_score(*ops.dists_forward(y, x, packed[prec], prec), alpha, beta)
+        c = ops.dists_score(*ops.dists_forward(x[1:2], y[1:2], packed[prec], prec), alpha, beta)
+        assert (a - b).abs().max().item() < 1e-6
+        assert abs(a[1].item() - c[0].item()) < 1e-6

@@ -1,0 +1,120 @@
+"""Operator-level parity of the HIP kernels against the CPU oracle (GPU box only).
+
+Every call goes through the C ABI (nerf_qa_amd.ops -> libnqa_hip.so).  Tolerances:
+  f32  : accumulation-order differences only            -> 2e-5 relative to the map's scale
+  f16  : + one rounding of each stored activation (2^-11)
+  bf16 : + one rounding of each stored activation (2^-8)
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+PRECS = ["f32", "f16", "bf16"]
+DT = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}
+OUT_RTOL = {"f32": 2e-5, "f16": 1.2e-3, "bf16": 9e-3}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def packed(np_convs, dev):
+    from nerf_qa_amd import ops
+    return {p: ops.pack_vgg_weights(np_convs, p).to(dev) for p in PRECS}
+
+
+def _rand(shape, seed, lo=0.0, hi=1.0):
+    from nerf_qa_amd import synth
+    n = int(np.prod(shape))
+    return torch.from_numpy((synth.uniform(seed, n) * (hi - lo) + lo).astype(np.float32).reshape(shape))
+
+
+def _close(got, ref, rtol, what):
+    scale = ref.abs().max().item() + 1e-30
+    err = (got - ref).abs().max().item()
+    assert err <= rtol * scale, f"{what}: max abs err {err:.3e} vs scale {scale:.3e} (rtol {rtol})"
+    return err / scale
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("shape", [(2, 3, 37, 53), (1, 3, 16, 16), (3, 3, 5, 70)])
+def test_conv1_1(prec, shape, np_convs, packed, dev):
+    from nerf_qa_amd import ops
+    x = _rand(shape, 11)
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    w, b = torch.from_numpy(np_convs[0][0]), torch.from_numpy(np_convs[0][1])
+    ref = F.relu(F.conv2d((x - mean) / std, w, b, padding=1))
+    out = ops.conv1_1(x.to(dev), packed[prec], prec)
+    assert out.dtype == DT[prec] and out.shape == (shape[0], shape[2], shape[3], 64)
+    got = out.float().permute(0, 3, 1, 2).cpu()
+    _close(got, ref, OUT_RTOL[prec], f"conv1_1[{prec}]")
+
+
+CONV_CASES = [  # (layer, n, H, W)
+    (1, 2, 13, 37), (1, 1, 32, 64), (1, 2, 9, 16),
+    (2, 2, 11, 40), (3, 1, 8, 33), (3, 3, 16, 16), (4, 1, 7, 7),
+    (6, 2, 12, 35), (7, 1, 6, 18), (9, 2, 9, 20), (12, 3, 4, 16), (12, 1, 2, 2),
+]
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("layer,n,h,w", CONV_CASES)
+def test_conv3x3_relu(prec, layer, n, h, w, np_convs, packed, dev):
+    from nerf_qa_amd import ops
+    cin = ops.CONV_CIN[layer]
+    # post-ReLU-like input: half zeros, rest in [0, 2); stored in the activation dtype
+    a = _rand((n, h, w, cin), 100 + layer, -2.0, 2.0).clamp_min(0).to(DT[prec])
+    wq = torch.from_numpy(np_convs[layer][0]).to(DT[prec]).float()
+    b = torch.from_numpy(np_convs[layer][1])
+    ref = F.relu(F.conv2d(a.float().permute(0, 3, 1, 2), wq, b, padding=1))
+    out = ops.conv3x3_relu(a.to(dev), layer, packed[prec], prec)
+    got = out.float().permute(0, 3, 1, 2).cpu()
+    _close(got, ref, OUT_RTOL[prec], f"conv layer {layer} [{prec}] {n}x{h}x{w}")
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("n,h,w,c", [(2, 9, 13, 64), (1, 16, 16, 128), (2, 1, 5, 256), (1, 7, 2, 512)])
+def test_l2pool(prec, n, h, w, c, dev):
+    from nerf_qa_amd import ops
+    from oracle import dists_oracle
+    a = _rand((n, h, w, c), 7, 0.0, 3.0).to(DT[prec])
+    ref = dists_oracle.l2pool(a.float().permute(0, 3, 1, 2))
+    out = ops.l2pool(a.to(dev), prec)
+    assert out.shape == (n, (h + 1) // 2, (w + 1) // 2, c)
+    _close(out.float().permute(0, 3, 1, 2).cpu(), ref, OUT_RTOL[prec], f"l2pool[{prec}]")
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_nhwc_to_nchw(prec, dev):
+    from nerf_qa_amd import ops
+    a = _rand((2, 5, 9, 72), 3).to(DT[prec])
+    out = ops.nhwc_to_nchw_f32(a.to(dev), prec).cpu()
+    assert torch.equal(out, a.float().permute(0, 3, 1, 2))
+
+
+def test_stats_nchw_and_score(alpha_beta, dev):
+    """forward_from_feats path: statistics on caller-provided NCHW maps + fused score."""
+    from nerf_qa_amd import ops
+    from oracle import dists_oracle
+    chns = (3, 64, 128, 256, 512, 512)
+    dims = [(33, 47), (33, 47), (17, 24), (9, 12), (5, 6), (3, 3)]
+    f0 = [_rand((2, c, h, w), 20 + k, 0, 2) for k, (c, (h, w)) in enumerate(zip(chns, dims))]
+    f1 = [(f + 0.3 * _rand(tuple(f.shape), 40 + k, -1, 1)).clamp_min(0) for k, f in enumerate(f0)]
+    f0[3][:, 5] = 0.0  # a dead channel on both sides: S2 must come out as exactly 1
+    f1[3][:, 5] = 0.0
+    r1, r2 = dists_oracle.dists_stats(f0, f1)
+    s1, s2 = ops.dists_stats_nchw([f.to(dev) for f in f0], [f.to(dev) for f in f1])
+    assert (s1.cpu() - r1).abs().max().item() < 2e-6
+    assert (s2.cpu() - r2).abs().max().item() < 2e-5
+    assert s2[0, 3 + 64 + 128 + 5].item() == 1.0
+    alpha, beta = alpha_beta
+    ref = dists_oracle.dists_score(r1, r2, alpha, beta)
+    got = ops.dists_score(s1, s2, alpha.to(dev), beta.to(dev)).cpu()
+    assert (got - ref).abs().max().item() < 2e-6
