@@ -1,0 +1,84 @@
+"""The CPU oracle against the golden vectors frozen from the imported reference
+(oracle/make_goldens.py), plus invariants of the reference algorithm it restates."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+
+def _inputs(g):
+    from nerf_qa_amd import synth
+    x, y = synth.frame_batch([int(s) for s in g["seeds"]], int(g["h"]), int(g["w"]), [str(k) for k in g["kinds"]])
+    return torch.from_numpy(x), torch.from_numpy(y)
+
+
+def test_weight_generator_fingerprint(np_convs):
+    g = np.load(os.path.join(GOLDEN, "vgg_fingerprint.npz"))
+    fp = np.array([[float(np.abs(w).sum()), float(b.sum())] for w, b in np_convs])
+    assert np.allclose(fp, g["fp"], rtol=1e-6, atol=0)
+
+
+DISTS_GOLD = sorted(glob.glob(os.path.join(GOLDEN, "dists_*.npz")))
+ADISTS_GOLD = sorted(glob.glob(os.path.join(GOLDEN, "adists_*.npz")))
+
+
+@pytest.mark.parametrize("path", DISTS_GOLD, ids=[os.path.basename(p)[:-4] for p in DISTS_GOLD])
+def test_dists_oracle_matches_reference_golden(path, oracle_convs, alpha_beta):
+    from oracle import dists_oracle
+    g = np.load(path)
+    x, y = _inputs(g)
+    alpha, beta = alpha_beta
+    f0, f1 = dists_oracle.vgg_pyramid(x, oracle_convs), dists_oracle.vgg_pyramid(y, oracle_convs)
+    s1, s2 = dists_oracle.dists_stats(f0, f1)
+    score = dists_oracle.dists_score(s1, s2, alpha, beta)
+    assert np.abs(score.numpy() - g["score"]).max() <= 1e-6
+    assert np.abs(s1.numpy() - g["s1"]).max() <= 1e-5
+    assert np.abs(s2.numpy() - g["s2"]).max() <= 1e-5
+    summ = np.array([[f.mean().item(), f.abs().mean().item(), f.abs().max().item()] for f in f0])
+    assert np.allclose(summ, g["feat_x"], rtol=1e-5)
+    avg = dists_oracle.dists(x, y, oracle_convs, alpha, beta, batch_average=True)
+    assert abs(avg.item() - float(g["score_avg"])) <= 1e-6
+
+
+@pytest.mark.parametrize("path", ADISTS_GOLD, ids=[os.path.basename(p)[:-4] for p in ADISTS_GOLD])
+def test_adists_oracle_matches_reference_golden(path, oracle_convs):
+    from oracle import adists_oracle
+    g = np.load(path)
+    x, y = _inputs(g)
+    score = adists_oracle.adists(x, y, oracle_convs, as_loss=False)
+    assert np.abs(score.numpy() - g["score"]).max() <= 2e-6
+    loss = adists_oracle.adists(x, y, oracle_convs, as_loss=True)
+    assert abs(loss.item() - float(g["loss"])) <= 2e-6
+
+
+def test_l2pool_filter_and_shape():
+    from oracle import dists_oracle
+    f = dists_oracle.hanning_filter()
+    assert torch.equal(f, torch.tensor([[1., 2., 1.], [2., 4., 2.], [1., 2., 1.]]) / 16)
+    x = torch.rand(1, 4, 7, 10)
+    assert dists_oracle.l2pool(x).shape == (1, 4, 4, 5)
+
+
+def test_pyramid_shapes_odd(oracle_convs):
+    from oracle import dists_oracle
+    feats = dists_oracle.vgg_pyramid(torch.rand(1, 3, 97, 131), oracle_convs)
+    assert [tuple(f.shape[1:]) for f in feats] == [(3, 97, 131), (64, 97, 131), (128, 49, 66), (256, 25, 33),
+                                                   (512, 13, 17), (512, 7, 9)]
+
+
+def test_project_weights(alpha_beta):
+    from oracle import dists_oracle
+    a, b = dists_oracle.project_weights(*alpha_beta)
+    assert abs((a.sum() + b.sum()).item() - 1.0) < 1e-6
+    assert a[:, :3].min().item() > 0.019 and b[:, :3].min().item() > 0.019
+
+
+def test_adists_window_switch():
+    from oracle import adists_oracle
+    assert adists_oracle.windowed(21, 21) and not adists_oracle.windowed(20, 300)
+    g = adists_oracle.gaussian_1d()
+    assert g.numel() == 21 and abs(g.sum().item() - 1) < 1e-6 and g.argmax().item() == 10
