@@ -1,0 +1,91 @@
+"""Drop-in `ADISTS` for nerf_qa.ADISTS.ADISTS, computed by libnqa_hip.so.
+
+Mirrors nerf_qa/ADISTS/ADISTS.py:
+  ADISTS(window_size=21)                                  :36-69
+  .forward(x, y, as_loss=True, as_map=False)              :137-197
+  .forward_once(x)                                        :112-125
+Asymmetric like the reference: texture probabilities and entropy weights come from x
+only (:147,153), so callers pass x = reference frame (prep.py:186).
+
+as_loss=True in the reference runs the pyramids WITH autograd (:139-141); this build has
+no VGG backward, so the value 1-mean(D) is returned without a graph.  as_map=True (the
+[B,B,H,W] distortion map, :188-193) is outside the hot path and raises.
+"""
+from __future__ import annotations
+
+import math
+import os
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .._lib import prec_id
+from ..DISTS_pytorch.DISTS_pt import DEFAULT_PRECISION, L2pooling as Downsample, _build_stages  # noqa: F401
+from ..vgg_weights import load_vgg16_convs
+
+
+class ADISTS(torch.nn.Module):
+    def __init__(self, window_size=21, precision=None, vgg16_path=None):
+        super().__init__()
+        if window_size != 21:
+            raise NotImplementedError("the HIP windowed-statistics kernel is built for the 21x21 window "
+                                      "the reference always uses")
+        convs, self.vgg_source = load_vgg16_convs(vgg16_path)
+        self.stage1, self.stage2, self.stage3, self.stage4, self.stage5 = _build_stages(convs)
+        for param in self.parameters():
+            param.requires_grad = False
+        self.register_buffer("mean", torch.tensor([0.485, 0.456, 0.406]).view(1, -1, 1, 1))
+        self.register_buffer("std", torch.tensor([0.229, 0.224, 0.225]).view(1, -1, 1, 1))
+        self.chns = [3, 64, 128, 256, 512, 512]
+        self.windows = nn.ParameterList()
+        self.window_size = window_size
+        for k in range(len(self.chns)):
+            self.windows.append(self.create_window(self.window_size, self.window_size / 3, self.chns[k]))
+        self.precision = precision or os.environ.get("NQA_PRECISION", DEFAULT_PRECISION)
+        prec_id(self.precision)
+        self._packed = None
+        self._packed_key = None
+        self._ws = ops.Workspace()
+
+    # the window parameters are kept for state_dict compatibility (ADISTS.py:66-69,102-110);
+    # the kernel uses the same separable 1-D Gaussian
+    def gaussian(self, window_size, sigma):
+        gauss = torch.Tensor([math.exp(-(x - window_size // 2) ** 2 / float(2 * sigma ** 2))
+                              for x in range(window_size)])
+        return gauss / gauss.sum()
+
+    def create_window(self, window_size, window_sigma, channel):
+        _1d = self.gaussian(window_size, window_sigma).unsqueeze(1)
+        _2d = _1d.mm(_1d.t()).float().unsqueeze(0).unsqueeze(0)
+        return nn.Parameter(_2d.expand(channel, 1, window_size, window_size).contiguous(), requires_grad=False)
+
+    def _conv_modules(self):
+        return [m for st in (self.stage1, self.stage2, self.stage3, self.stage4, self.stage5)
+                for m in st if isinstance(m, nn.Conv2d)]
+
+    def _packed_weights(self, dev):
+        convs = self._conv_modules()
+        key = (str(dev), self.precision) + tuple((m.weight._version, m.weight.data_ptr()) for m in convs)
+        if self._packed is None or self._packed_key != key:
+            blob = ops.pack_vgg_weights([(m.weight, m.bias) for m in convs], self.precision)
+            self._packed, self._packed_key = blob.to(dev), key
+        return self._packed
+
+    def __getstate__(self):
+        d = self.__dict__.copy()
+        d["_packed"], d["_packed_key"], d["_ws"] = None, None, ops.Workspace()
+        return d
+
+    def forward_once(self, x):
+        taps = ops.vgg_pyramid(x, self._packed_weights(x.device), self.precision, self._ws)
+        return [x] + [ops.nhwc_to_nchw_f32(t, self.precision) for t in taps]
+
+    def forward(self, x, y, as_loss=True, as_map=False):
+        assert x.shape == y.shape
+        if as_map:
+            raise NotImplementedError("as_map=True (the full-resolution distortion map) is not part of this build")
+        d = ops.adists_forward(x, y, self._packed_weights(x.device), self.precision, self._ws)
+        if as_loss:
+            return 1 - d.mean()
+        return 1 - d

@@ -1,0 +1,193 @@
+"""Drop-in `DISTS` for nerf_qa.DISTS_pytorch.DISTS_pt.DISTS, computed by libnqa_hip.so.
+
+Mirrors the reference's callable surface (nerf_qa/DISTS_pytorch/DISTS_pt.py):
+  DISTS(load_weights=True, from_feats=False)                       :27-80
+  .forward(x, y, require_grad=False, batch_average=False,
+           warp=None, certainty=None)                              :105-148
+  .forward_once(x) -> [x, relu1_2, relu2_2, relu3_3, relu4_3, relu5_3]   :91-103
+  .forward_from_feats(feats0, feats1, batch_average=False)         :181-208
+  .project_weights()                                               :82-89
+  prepare_image(image, resize=True, keep_aspect_ratio=False)       :210-217
+and keeps the attributes callers read: alpha, beta (nn.Parameter (1,1475,1,1)), chns,
+stage1..stage5 (nn.Sequential holding the frozen fp32 Conv2d weights, same child names),
+mean, std.
+
+What runs where: the 13 conv3x3+ReLU, the 4 L2-pools and all statistics are HIP kernels
+(ops.dists_forward).  PyTorch only holds memory and, when alpha/beta need gradients (the
+fine-tuning loop, run_nerf_qa.py:433-461), evaluates the 2950-term weighted sum so that
+autograd reaches alpha and beta without a custom backward.  CPU tensors are refused.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .._lib import NqaError, prec_id
+from ..vgg_weights import load_vgg16_convs
+
+_DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data", "dists_alpha_beta.npz")
+DEFAULT_PRECISION = "f16"  # meets |dscore| <= 1e-4 (tests/test_gpu_dists.py); "f32" is exact-f32 MFMA, "bf16" opt-in
+
+
+class L2pooling(nn.Module):
+    """Parameter holder with the reference's buffer name/shape (DISTS_pt.py:11-25).
+
+    The arithmetic is nqa_l2pool (HIP); this module exists so `stageN` keeps the same
+    children and state_dict keys as the reference's.
+    """
+
+    def __init__(self, filter_size=5, stride=2, channels=None, pad_off=0):
+        super().__init__()
+        self.padding = (filter_size - 2) // 2
+        self.stride = stride
+        self.channels = channels
+        a = np.hanning(filter_size)[1:-1]
+        g = torch.Tensor(a[:, None] * a[None, :])
+        g = g / torch.sum(g)
+        self.register_buffer("filter", g[None, None, :, :].repeat((self.channels, 1, 1, 1)))
+
+    def forward(self, input):
+        raise NqaError("L2pooling runs inside the HIP pyramid (DISTS.forward / forward_once); "
+                       "calling the stage modules directly is not supported")
+
+
+def _build_stages(convs):
+    """stage1..5 with torchvision's child indices (DISTS_pt.py:36-49)."""
+    idx = (0, 2, 5, 7, 10, 12, 14, 17, 19, 21, 24, 26, 28)
+    layers = {}
+    for i, (w, b) in zip(idx, convs):
+        m = nn.Conv2d(w.shape[1], w.shape[0], kernel_size=3, padding=1)
+        m.weight.data = w.clone()
+        m.bias.data = b.clone()
+        layers[i] = m
+        layers[i + 1] = nn.ReLU(inplace=True)
+    stages = [nn.Sequential() for _ in range(5)]
+    spans = ((0, 4), (5, 9), (10, 16), (17, 23), (24, 30))
+    pools = (None, (4, 64), (9, 128), (16, 256), (23, 512))
+    for s, (lo, hi) in enumerate(spans):
+        if pools[s]:
+            stages[s].add_module(str(pools[s][0]), L2pooling(channels=pools[s][1]))
+        for i in range(lo, hi):
+            stages[s].add_module(str(i), layers[i])
+    return stages
+
+
+class DISTS(torch.nn.Module):
+    def __init__(self, load_weights=True, from_feats=False, precision=None, vgg16_path=None):
+        super().__init__()
+        convs, self.vgg_source = load_vgg16_convs(vgg16_path)
+        self.stage1, self.stage2, self.stage3, self.stage4, self.stage5 = _build_stages(convs)
+        for param in self.parameters():
+            param.requires_grad = False
+
+        self.register_buffer("mean", torch.tensor([0.485, 0.456, 0.406]).view(1, -1, 1, 1))
+        self.register_buffer("std", torch.tensor([0.229, 0.224, 0.225]).view(1, -1, 1, 1))
+
+        self.chns = [3, 64, 128, 256, 512, 512]
+        self.register_parameter("alpha", nn.Parameter(torch.randn(1, sum(self.chns), 1, 1)))
+        self.register_parameter("beta", nn.Parameter(torch.randn(1, sum(self.chns), 1, 1)))
+        self.alpha.data.normal_(0.1, 0.01)
+        self.beta.data.normal_(0.1, 0.01)
+        if load_weights:
+            # the published DISTS alpha/beta (the reference reads them from sys.prefix/weights.pt, :63,79-80)
+            ab = np.load(_DATA)
+            self.alpha.data = torch.from_numpy(ab["alpha"]).view(1, -1, 1, 1).clone()
+            self.beta.data = torch.from_numpy(ab["beta"]).view(1, -1, 1, 1).clone()
+
+        self.precision = precision or os.environ.get("NQA_PRECISION", DEFAULT_PRECISION)
+        prec_id(self.precision)  # validate early
+        self._packed = None
+        self._packed_key = None
+        self._ws = ops.Workspace()
+
+    # ---- plumbing -----------------------------------------------------------------
+    def _conv_modules(self):
+        return [m for st in (self.stage1, self.stage2, self.stage3, self.stage4, self.stage5)
+                for m in st if isinstance(m, nn.Conv2d)]
+
+    def _packed_weights(self, dev):
+        convs = self._conv_modules()
+        key = (str(dev), self.precision) + tuple((m.weight._version, m.weight.data_ptr()) for m in convs)
+        if self._packed is None or self._packed_key != key:
+            blob = ops.pack_vgg_weights([(m.weight, m.bias) for m in convs], self.precision)
+            self._packed, self._packed_key = blob.to(dev), key
+        return self._packed
+
+    def __getstate__(self):  # torch.save(model) (run_nerf_qa.py:502): drop device scratch
+        d = self.__dict__.copy()
+        d["_packed"], d["_packed_key"], d["_ws"] = None, None, ops.Workspace()
+        return d
+
+    def _similarities(self, x, y):
+        if x.shape != y.shape:
+            raise ValueError(f"x and y differ in shape: {tuple(x.shape)} vs {tuple(y.shape)}")
+        return ops.dists_forward(x, y, self._packed_weights(x.device), self.precision, self._ws)
+
+    def _weighted(self, s1, s2, batch_average):
+        """score from S1,S2; DISTS_pt.py:123-148."""
+        if torch.is_grad_enabled() and (self.alpha.requires_grad or self.beta.requires_grad):
+            alpha, beta = self.alpha.view(1, -1), self.beta.view(1, -1)
+            w_sum = alpha.sum() + beta.sum()
+            dist1 = dist2 = 0
+            o = 0
+            for c in self.chns:
+                dist1 = dist1 + ((alpha[:, o:o + c] / w_sum) * s1[:, o:o + c]).sum(1, keepdim=True)
+                dist2 = dist2 + ((beta[:, o:o + c] / w_sum) * s2[:, o:o + c]).sum(1, keepdim=True)
+                o += c
+            score = 1 - (dist1 + dist2).squeeze(1)
+        else:
+            score = ops.dists_score(s1, s2, self.alpha, self.beta)
+        return score.mean() if batch_average else score
+
+    # ---- reference surface ------------------------------------------------------------
+    def project_weights(self):
+        lower_bound = torch.zeros_like(self.alpha.data)
+        lower_bound[:, :3, :, :] = 0.02
+        alpha = torch.max(self.alpha.data, lower_bound)
+        beta = torch.max(self.beta.data, lower_bound)
+        weight_sum = torch.cat([alpha, beta], dim=1).sum()
+        self.alpha.data = alpha / weight_sum
+        self.beta.data = beta / weight_sum
+
+    def forward_once(self, x):
+        taps = ops.vgg_pyramid(x, self._packed_weights(x.device), self.precision, self._ws)
+        return [x] + [ops.nhwc_to_nchw_f32(t, self.precision) for t in taps]
+
+    def forward(self, x, y, require_grad=False, batch_average=False, warp=None, certainty=None):
+        if require_grad:
+            raise NotImplementedError("require_grad=True needs a backward pass through the VGG pyramid, which "
+                                      "this build does not have; no caller in nerf-qa's FR path uses it")
+        s1, s2 = self._similarities(x, y)
+        return self._weighted(s1, s2, batch_average)
+
+    def forward_from_feats(self, feats0, feats1, batch_average=False):
+        if torch.is_grad_enabled() and any(f.requires_grad for f in list(feats0) + list(feats1)):
+            raise NotImplementedError("forward_from_feats on grad-carrying features (the NR decoder, "
+                                      "model_nr_v8.py:258-265) is outside this build's scope")
+        s1, s2 = ops.dists_stats_nchw(feats0, feats1)
+        return self._weighted(s1, s2, batch_average)
+
+
+def prepare_image(image, resize=True, keep_aspect_ratio=False):
+    """PIL image -> float32 (1,3,H,W) in [0,1]; DISTS_pt.py:210-217 without torchvision.
+
+    torchvision's resize of a PIL image is PIL's own antialiased bilinear `Image.resize`;
+    `resize(image, 256)` scales the short side to 256 keeping the aspect ratio.
+    """
+    from PIL import Image
+    if resize and min(image.size) > 256:
+        if keep_aspect_ratio:
+            w, h = image.size
+            if w <= h:
+                nw, nh = 256, int(256 * h / w)
+            else:
+                nh, nw = 256, int(256 * w / h)
+            image = image.resize((nw, nh), Image.BILINEAR)
+        else:
+            image = image.resize((256, 256), Image.BILINEAR)
+    arr = np.asarray(image.convert("RGB"), dtype=np.uint8)
+    return torch.from_numpy(arr).permute(2, 0, 1).float().div(255).unsqueeze(0)

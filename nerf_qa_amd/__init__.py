@@ -1,0 +1,4 @@
+"""MI355X-native DISTS / A-DISTS hot path of kobejean/nerf-qa."""
+from ._lib import NqaError  # noqa: F401
+
+__all__ = ["NqaError"]

@@ -1,20 +1,801 @@
-// A-DISTS kernels (nerf_qa/ADISTS/ADISTS.py:71-197).  Placeholder until the windowed
-// statistics kernels land: the entry points exist so the ABI is complete and fail loudly.
+// A-DISTS on gfx950: everything after the two VGG pyramids of ADISTS.forward
+// (nerf_qa/ADISTS/ADISTS.py:137-197, as_map=False).
+//
+// The reference runs, per stage, 2 depthwise 21x21 Gaussian convolutions for the texture
+// probability (compute_prob, :71-100) and 5 more for the windowed T/S maps (:165-183), on
+// L2-normalised features.  Three observations shape the kernels here:
+//   * the window is an outer product (:106-110), so each filter is two 21-tap passes;
+//   * F.normalize(f, dim=(2,3)) is one scalar per (image, channel), so the windowed moments
+//     of the normalised maps are the moments of the raw maps times inv_x, inv_y, inv_x^2 ...;
+//     the raw x moments also give compute_prob's mean/variance -- one windowed pass serves both;
+//   * D = sum_c w_c mean_hw((1-ps) T_c + ps S_c) = mean_hw((1-ps) TW + ps SW) with
+//     TW = sum_c w_c T_c, SW = sum_c w_c S_c, so the heavy pass reduces over channels and
+//     leaves three small (B,h-20,w-20) maps; the coarse-to-fine probability chain then
+//     works on those maps only.
+// Global per-(image,channel) sums come from the DISTS statistics kernels (fp64).
+#include <math.h>
+#include <string.h>
+
 #include "nqa_common.h"
+
+namespace nqa {
+
+static constexpr int kWin = 21;
+static constexpr int kTile = 16;            // output tile edge
+static constexpr int kHalo = kTile + kWin - 1;  // 36
+
+struct Gauss {
+  float g[kWin];
+};
+
+// ---------------------------------------------------------------------------------
+// (b,3,H,W) float32 NCHW -> (b,H,W,4) float32 NHWC with a zero 4th channel (stage 0)
+__global__ __launch_bounds__(256) void nchw3_to_nhwc4_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                             int HW) {
+  const int p = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
+  if (p >= HW) return;
+  const float *s = in + (size_t)n * 3 * HW;
+  f32x4 v = {s[p], s[HW + p], s[2 * HW + p], 0.f};
+  *reinterpret_cast<f32x4 *>(out + ((size_t)n * HW + p) * 4) = v;
+}
+
+// ---------------------------------------------------------------------------------
+// Per (b, channel) scalars from the fp64 partial sums (layout of stats_*_kernel):
+//   q[0]=inv_x  q[1]=inv_y   1/max(||f||_2, 1e-12)               (ADISTS.py:130,166-167)
+//   q[2]=sum_x               for the entropy normalisation       (:132)
+//   q[3..7]= mean_x mean_y var_x var_y cov of the RAW maps (population), for the global branch
+__global__ __launch_bounds__(256) void adists_prep_kernel(const double *__restrict__ part, StageDesc d,
+                                                          float *__restrict__ q /* [8][B][ctot] */, int B) {
+  const int b = blockIdx.y;
+  const int gc = blockIdx.x * 256 + threadIdx.x;
+  if (gc >= d.ctot) return;
+  int k = 0;
+  while (k + 1 < d.nstage && gc >= d.coff[k + 1]) ++k;
+  const int c = gc - d.coff[k];
+  const double *p = part + d.part_off[k] + ((size_t)b * d.nblk[k] * d.c[k] + c) * 5;
+  double s[5] = {0, 0, 0, 0, 0};
+  for (int blk = 0; blk < d.nblk[k]; ++blk)
+#pragma unroll
+    for (int j = 0; j < 5; ++j) s[j] += p[(size_t)blk * d.c[k] * 5 + j];
+  const double inv = 1.0 / (double)d.hw[k];
+  const double mx = s[0] * inv, my = s[1] * inv;
+  const size_t o = (size_t)b * d.ctot + gc, st = (size_t)B * d.ctot;
+  q[0 * st + o] = (float)(1.0 / fmax(sqrt(s[2]), 1e-12));
+  q[1 * st + o] = (float)(1.0 / fmax(sqrt(s[3]), 1e-12));
+  q[2 * st + o] = (float)s[0];
+  q[3 * st + o] = (float)mx;
+  q[4 * st + o] = (float)my;
+  q[5 * st + o] = (float)(s[2] * inv - mx * mx);
+  q[6 * st + o] = (float)(s[3] * inv - my * my);
+  q[7 * st + o] = (float)(s[4] * inv - mx * my);
+}
+
+// ---------------------------------------------------------------------------------
+// Spatial entropy of the x maps (ADISTS.py:127-133): p = relu(f)*inv; p /= sum(p)+c0;
+// H = -sum p log2(p + c0).  Partial sums per block, part[(b*nblk+blk)*C + c].
+template <typename P>
+__global__ __launch_bounds__(256) void entropy_nhwc_kernel(const typename P::T *__restrict__ feat, int HW, int C,
+                                                           int pix_per_block, const float *__restrict__ invx,
+                                                           const float *__restrict__ sumx, int ctot,
+                                                           double *__restrict__ part) {
+  typedef typename P::T T;
+  typedef __attribute__((ext_vector_type(P::CPC))) T tvec;
+  __shared__ double red[256 * P::CPC];
+  const int tid = threadIdx.x, b = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
+  const int G = C / P::CPC, PL = 256 / G;
+  const int g = tid % G, pl = tid / G;
+  float inv[P::CPC], den[P::CPC];
+#pragma unroll
+  for (int e = 0; e < P::CPC; ++e) {
+    inv[e] = invx[(size_t)b * ctot + g * P::CPC + e];
+    den[e] = inv[e] * sumx[(size_t)b * ctot + g * P::CPC + e] + 1e-12f;
+  }
+  double acc[P::CPC];
+#pragma unroll
+  for (int e = 0; e < P::CPC; ++e) acc[e] = 0.0;
+  const T *f = feat + (size_t)b * HW * C + g * P::CPC;
+  const int p_end = min(HW, (blk + 1) * pix_per_block);
+  for (int p = blk * pix_per_block + pl; p < p_end; p += PL) {
+    const tvec v = *reinterpret_cast<const tvec *>(f + (size_t)p * C);
+#pragma unroll
+    for (int e = 0; e < P::CPC; ++e) {
+      const float pn = fmaxf(P::to_f(v[e]), 0.f) * inv[e] / den[e];
+      acc[e] += (double)(-pn * log2f(pn + 1e-12f));
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < P::CPC; ++e) red[tid * P::CPC + e] = acc[e];
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    const int cg = c / P::CPC, ce = c % P::CPC;
+    double s = 0.0;
+    for (int q = 0; q < PL; ++q) s += red[(q * G + cg) * P::CPC + ce];
+    part[((size_t)b * nblk + blk) * C + c] = s;
+  }
+}
+
+// Channel weights (ADISTS.py:134-135,154-160): per stage H/(sum_stage H + c0)*C, then over
+// all 1475: /sum, clamp to mean +- 0.5*population std, /sum.  One block per image.
+struct EntDesc {
+  long part_off[NQA_NUM_TAPS];
+  int nblk[NQA_NUM_TAPS];
+  int c[NQA_NUM_TAPS];      // padded channel count used by the partial layout (stage 0: 4)
+  int creal[NQA_NUM_TAPS];  // real channels
+  int coff[NQA_NUM_TAPS];
+  int ctot;
+};
+
+__global__ __launch_bounds__(256) void adists_weights_kernel(const double *__restrict__ part, EntDesc d,
+                                                             float *__restrict__ wgt /* [B][ctot] */) {
+  __shared__ float h[NQA_TOTAL_CHNS];
+  __shared__ double red[256];
+  __shared__ double bc[2];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  auto block_sum = [&](double v) -> double {
+    __syncthreads();
+    red[tid] = v;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if (tid < off) red[tid] += red[tid + off];
+      __syncthreads();
+    }
+    return red[0];
+  };
+  for (int k = 0; k < NQA_NUM_TAPS; ++k) {
+    double loc = 0.0;
+    for (int c = tid; c < d.creal[k]; c += 256) {
+      const double *p = part + d.part_off[k] + (size_t)b * d.nblk[k] * d.c[k] + c;
+      double s = 0.0;
+      for (int blk = 0; blk < d.nblk[k]; ++blk) s += p[(size_t)blk * d.c[k]];
+      h[d.coff[k] + c] = (float)s;
+      loc += (double)(float)s;
+    }
+    const float tot = (float)block_sum(loc);
+    for (int c = tid; c < d.creal[k]; c += 256)
+      h[d.coff[k] + c] = h[d.coff[k] + c] / (tot + 1e-12f) * (float)d.creal[k];
+  }
+  __syncthreads();
+  double loc = 0.0;
+  for (int c = tid; c < d.ctot; c += 256) loc += (double)h[c];
+  const float s0 = (float)block_sum(loc);
+  for (int c = tid; c < d.ctot; c += 256) h[c] = h[c] / s0;
+  __syncthreads();
+  loc = 0.0;
+  for (int c = tid; c < d.ctot; c += 256) loc += (double)h[c];
+  const float mean = (float)(block_sum(loc) / d.ctot);
+  loc = 0.0;
+  for (int c = tid; c < d.ctot; c += 256) {
+    const float dv = h[c] - mean;
+    loc += (double)(dv * dv);
+  }
+  const float sd = sqrtf((float)(block_sum(loc) / d.ctot));
+  const float lo = mean - 0.5f * sd, hi = mean + 0.5f * sd;
+  loc = 0.0;
+  for (int c = tid; c < d.ctot; c += 256) {
+    h[c] = fminf(fmaxf(h[c], lo), hi);
+    loc += (double)h[c];
+  }
+  const float s1 = (float)block_sum(loc);
+  (void)bc;
+  for (int c = tid; c < d.ctot; c += 256) wgt[(size_t)b * d.ctot + c] = h[c] / s1;
+}
+
+// ---------------------------------------------------------------------------------
+// The windowed pass of one stage.  Block = 16x16 output pixels of image pair b; loop over
+// channel quads: stage a 36x36 halo of x and y (fp32) in LDS, 21-tap horizontal pass of the
+// five products into LDS, 21-tap vertical pass per output pixel, then T/S/gamma per channel.
+template <typename P>
+__global__ __launch_bounds__(256) void adists_window_kernel(const typename P::T *__restrict__ fx,
+                                                            const typename P::T *__restrict__ fy, int H, int W, int C,
+                                                            int creal, const float *__restrict__ q, int B, int ctot,
+                                                            int coff, const float *__restrict__ wgt, Gauss gw,
+                                                            float *__restrict__ gamma, float *__restrict__ tw,
+                                                            float *__restrict__ sw) {
+  typedef typename P::T T;
+  typedef __attribute__((ext_vector_type(4))) T t4;
+  extern __shared__ __attribute__((aligned(16))) char dyn[];
+  f32x4 *sx = reinterpret_cast<f32x4 *>(dyn);                 // [36][36]
+  f32x4 *sy = sx + kHalo * kHalo;                              // [36][36]
+  f32x4 *hb = sy + kHalo * kHalo;                              // [5][36][16]
+  const int tid = threadIdx.x, b = blockIdx.z;
+  const int ox0 = blockIdx.x * kTile, oy0 = blockIdx.y * kTile;
+  const int Ho = H - (kWin - 1), Wo = W - (kWin - 1);
+  const int ty = tid >> 4, tx = tid & 15;
+  const T *px = fx + (size_t)b * H * W * C;
+  const T *py = fy + (size_t)b * H * W * C;
+  const size_t st = (size_t)B * ctot, qo = (size_t)b * ctot + coff;
+  float g_acc = 0.f, t_acc = 0.f, s_acc = 0.f;
+  for (int c0 = 0; c0 < C; c0 += 4) {
+    __syncthreads();
+    for (int i = tid; i < kHalo * kHalo; i += 256) {
+      const int r = i / kHalo, cc = i - r * kHalo;
+      const int gy = oy0 + r, gx = ox0 + cc;
+      f32x4 vx = {0.f, 0.f, 0.f, 0.f}, vy = vx;
+      if (gy < H && gx < W) {
+        const size_t o = ((size_t)gy * W + gx) * C + c0;
+        const t4 ax = *reinterpret_cast<const t4 *>(px + o), ay = *reinterpret_cast<const t4 *>(py + o);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          vx[e] = P::to_f(ax[e]);
+          vy[e] = P::to_f(ay[e]);
+        }
+      }
+      sx[i] = vx;
+      sy[i] = vy;
+    }
+    __syncthreads();
+    for (int i = tid; i < kHalo * kTile; i += 256) {
+      const int r = i >> 4, cc = i & 15;
+      f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0, a4 = a0;
+#pragma unroll
+      for (int k = 0; k < kWin; ++k) {
+        const f32x4 vx = sx[r * kHalo + cc + k], vy = sy[r * kHalo + cc + k];
+        const float g = gw.g[k];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float gx_ = g * vx[e], gy_ = g * vy[e];
+          a0[e] += gx_;
+          a1[e] += gy_;
+          a2[e] = fmaf(gx_, vx[e], a2[e]);
+          a3[e] = fmaf(gy_, vy[e], a3[e]);
+          a4[e] = fmaf(gx_, vy[e], a4[e]);
+        }
+      }
+      hb[0 * kHalo * kTile + i] = a0;
+      hb[1 * kHalo * kTile + i] = a1;
+      hb[2 * kHalo * kTile + i] = a2;
+      hb[3 * kHalo * kTile + i] = a3;
+      hb[4 * kHalo * kTile + i] = a4;
+    }
+    __syncthreads();
+    f32x4 m[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) m[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < kWin; ++k) {
+      const float g = gw.g[k];
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const f32x4 v = hb[j * kHalo * kTile + (ty + k) * kTile + tx];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m[j][e] = fmaf(g, v[e], m[j][e]);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = c0 + e;
+      if (c < creal) {
+        const float ix = q[0 * st + qo + c], iy = q[1 * st + qo + c], w = wgt[qo + c];
+        const float rmx = m[0][e], rex2 = m[2][e];
+        g_acc += (rex2 - rmx * rmx) / (rmx + 1e-12f);
+        const float mx = ix * rmx, my = iy * m[1][e];
+        const float vx = ix * ix * rex2 - mx * mx, vy = iy * iy * m[3][e] - my * my;
+        const float cov = ix * iy * m[4][e] - mx * my;
+        const float t = (2.f * mx * my + 1e-6f) / (mx * mx + my * my + 1e-6f);
+        const float s = (2.f * cov + 1e-6f) / (vx + vy + 1e-6f);
+        t_acc = fmaf(w, t, t_acc);
+        s_acc = fmaf(w, s, s_acc);
+      }
+    }
+  }
+  const int oy = oy0 + ty, ox = ox0 + tx;
+  if (oy < Ho && ox < Wo) {
+    const size_t o = ((size_t)b * Ho + oy) * Wo + ox;
+    gamma[o] = g_acc / (float)creal;
+    tw[o] = t_acc;
+    sw[o] = s_acc;
+  }
+}
+
+// Global branch of one stage (maps smaller than the window; ADISTS.py:91-97,176-180): one
+// block per image pair, from the per-channel global statistics.  Outputs 1x1 "maps".
+__global__ __launch_bounds__(256) void adists_global_kernel(const float *__restrict__ q, int B, int ctot, int coff,
+                                                            int creal, const float *__restrict__ wgt,
+                                                            float *__restrict__ gamma, float *__restrict__ tw,
+                                                            float *__restrict__ sw) {
+  __shared__ double red[3][256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const size_t st = (size_t)B * ctot, qo = (size_t)b * ctot + coff;
+  double g = 0, t = 0, s = 0;
+  for (int c = tid; c < creal; c += 256) {
+    const float ix = q[0 * st + qo + c], iy = q[1 * st + qo + c], w = wgt[qo + c];
+    const float rmx = q[3 * st + qo + c], rmy = q[4 * st + qo + c];
+    const float rvx = q[5 * st + qo + c], rvy = q[6 * st + qo + c], rcov = q[7 * st + qo + c];
+    g += (double)(rvx / (rmx + 1e-12f));
+    const float mx = ix * rmx, my = iy * rmy;
+    const float vx = ix * ix * rvx, vy = iy * iy * rvy, cov = ix * iy * rcov;
+    t += (double)(w * ((2.f * mx * my + 1e-6f) / (mx * mx + my * my + 1e-6f)));
+    s += (double)(w * ((2.f * cov + 1e-6f) / (vx + vy + 1e-6f)));
+  }
+  red[0][tid] = g;
+  red[1][tid] = t;
+  red[2][tid] = s;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (tid < off)
+      for (int j = 0; j < 3; ++j) red[j][tid] += red[j][tid + off];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    gamma[b] = (float)(red[0][0] / creal);
+    tw[b] = (float)red[1][0];
+    sw[b] = (float)red[2][0];
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Probability chain on the small maps (compute_prob, ADISTS.py:77-99) and the stage's D.
+struct ChainAcc {       // one per (stage, image); zeroed before the chain
+  double sum, sumsq;    // of gamma
+  unsigned ps_min, ps_max, pp_min, pp_max;  // float bit patterns (values >= 0)
+  double dsum;          // sum over the map of (1-ps) TW + ps SW
+};
+
+__device__ inline float sigmoid_ref(float z) { return 1.f / (1.f + expf(-z)); }
+
+__device__ inline void zscore(const ChainAcc &a, int n, float &mean, float &sd) {
+  const double m = a.sum / n;
+  mean = (float)m;
+  double v = (a.sumsq - n * m * m) / (double)(n - 1);  // unbiased; n==1 -> 0/0 = NaN as torch.std
+  if (v < 0.0) v = 0.0;                                  // rounding of a constant map (NaN stays NaN)
+  sd = (float)sqrt(v);
+}
+
+__global__ __launch_bounds__(256) void chain_init_kernel(ChainAcc *acc, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    acc[i].sum = acc[i].sumsq = acc[i].dsum = 0.0;
+    acc[i].ps_min = acc[i].pp_min = 0x7F800000u;  // +inf
+    acc[i].ps_max = acc[i].pp_max = 0u;
+  }
+}
+
+__global__ __launch_bounds__(256) void chain_moments_kernel(const float *__restrict__ gamma, int n, ChainAcc *acc) {
+  __shared__ double red[2][256];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  double s = 0, s2 = 0;
+  for (int i = blockIdx.x * 256 + tid; i < n; i += gridDim.x * 256) {
+    const double g = gamma[(size_t)b * n + i];
+    s += g;
+    s2 += g * g;
+  }
+  red[0][tid] = s;
+  red[1][tid] = s2;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (tid < off) {
+      red[0][tid] += red[0][tid + off];
+      red[1][tid] += red[1][tid + off];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    atomicAdd(&acc[b].sum, red[0][0]);
+    atomicAdd(&acc[b].sumsq, red[1][0]);
+  }
+}
+
+__device__ inline void block_minmax(float lo, float hi, unsigned *gmin, unsigned *gmax) {
+  __shared__ float rl[256], rh[256];
+  const int tid = threadIdx.x;
+  rl[tid] = lo;
+  rh[tid] = hi;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (tid < off) {
+      rl[tid] = fminf(rl[tid], rl[tid + off]);
+      rh[tid] = fmaxf(rh[tid], rh[tid + off]);
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    atomicMin(gmin, __float_as_uint(rl[0]));
+    atomicMax(gmax, __float_as_uint(rh[0]));
+  }
+}
+
+__global__ __launch_bounds__(256) void chain_psminmax_kernel(const float *__restrict__ gamma, int n, ChainAcc *acc) {
+  const int b = blockIdx.y;
+  float mean, sd;
+  zscore(acc[b], n, mean, sd);
+  float lo = INFINITY, hi = 0.f;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const float ps = sigmoid_ref((gamma[(size_t)b * n + i] - mean) / (sd + 1e-12f));
+    lo = fminf(lo, ps);
+    hi = fmaxf(hi, ps);
+  }
+  block_minmax(lo, hi, &acc[b].ps_min, &acc[b].ps_max);
+}
+
+// bilinear sample of prev (hp x wp) at output (y,x) of an (h x w) grid, align_corners=True
+__device__ inline float bilinear_ac(const float *__restrict__ prev, int hp, int wp, int h, int w, int y, int x) {
+  const float sy = h > 1 ? (float)(hp - 1) / (float)(h - 1) : 0.f;
+  const float sx = w > 1 ? (float)(wp - 1) / (float)(w - 1) : 0.f;
+  const float ry = sy * y, rx = sx * x;
+  const int y0 = (int)ry, x0 = (int)rx;
+  const int y1 = y0 + (y0 < hp - 1 ? 1 : 0), x1 = x0 + (x0 < wp - 1 ? 1 : 0);
+  const float ly = ry - y0, lx = rx - x0;
+  const float hy = 1.f - ly, hx = 1.f - lx;
+  return hy * (hx * prev[y0 * wp + x0] + lx * prev[y0 * wp + x1]) +
+         ly * (hx * prev[y1 * wp + x0] + lx * prev[y1 * wp + x1]);
+}
+
+__device__ inline float pp_value(const float *gamma, const ChainAcc &a, int n, const float *prev, int hp, int wp,
+                                 int h, int w, int i, float mean, float sd) {
+  const float ps = sigmoid_ref((gamma[i] - mean) / (sd + 1e-12f));
+  const float lo = __uint_as_float(a.ps_min), hi = __uint_as_float(a.ps_max);
+  const float psn = (ps - lo) / (hi - lo + 1e-12f);
+  return psn * bilinear_ac(prev, hp, wp, h, w, i / w, i % w);
+}
+
+__global__ __launch_bounds__(256) void chain_ppminmax_kernel(const float *__restrict__ gamma, int h, int w,
+                                                             const float *__restrict__ prev, int hp, int wp,
+                                                             ChainAcc *acc) {
+  const int b = blockIdx.y, n = h * w;
+  float mean, sd;
+  zscore(acc[b], n, mean, sd);
+  float lo = INFINITY, hi = 0.f;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const float pp = pp_value(gamma + (size_t)b * n, acc[b], n, prev + (size_t)b * hp * wp, hp, wp, h, w, i, mean, sd);
+    lo = fminf(lo, pp);
+    hi = fmaxf(hi, pp);
+  }
+  block_minmax(lo, hi, &acc[b].pp_min, &acc[b].pp_max);
+}
+
+__global__ __launch_bounds__(256) void chain_final_kernel(const float *__restrict__ gamma, int h, int w,
+                                                          const float *__restrict__ prev, int hp, int wp,
+                                                          const float *__restrict__ tw, const float *__restrict__ sw,
+                                                          float *__restrict__ psprod, ChainAcc *acc) {
+  __shared__ double red[256];
+  const int b = blockIdx.y, n = h * w, tid = threadIdx.x;
+  float mean, sd;
+  zscore(acc[b], n, mean, sd);
+  const float lo = __uint_as_float(acc[b].pp_min), hi = __uint_as_float(acc[b].pp_max);
+  double d = 0.0;
+  for (int i = blockIdx.x * 256 + tid; i < n; i += gridDim.x * 256) {
+    const float pp = pp_value(gamma + (size_t)b * n, acc[b], n, prev + (size_t)b * hp * wp, hp, wp, h, w, i, mean, sd);
+    const float ps = (pp - lo) / (hi - lo + 1e-12f);
+    psprod[(size_t)b * n + i] = ps;
+    d += (double)((1.f - ps) * tw[(size_t)b * n + i] + ps * sw[(size_t)b * n + i]);
+  }
+  red[tid] = d;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (tid < off) red[tid] += red[tid + off];
+    __syncthreads();
+  }
+  if (tid == 0) atomicAdd(&acc[b].dsum, red[0]);
+}
+
+// global-branch stage: ps = sigmoid(gamma); ps_prod = ps * prev[0,0]; D = (1-ps_prod) TW + ps_prod SW
+__global__ void chain_global_kernel(const float *__restrict__ gamma, const float *__restrict__ prev, int hpwp,
+                                    const float *__restrict__ tw, const float *__restrict__ sw,
+                                    float *__restrict__ psprod, ChainAcc *acc, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float ps = sigmoid_ref(gamma[b]) * prev[(size_t)b * hpwp];
+  psprod[b] = ps;
+  acc[b].dsum = (double)((1.f - ps) * tw[b] + ps * sw[b]);
+}
+
+__global__ void ones_kernel(float *p, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 1.f;
+}
+
+// D_b = sum_k dsum_k / n_k
+struct DDesc {
+  int n[NQA_NUM_TAPS];
+};
+__global__ void adists_d_kernel(const ChainAcc *acc, DDesc d, int B, float *out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float s = 0.f;
+  for (int k = NQA_NUM_TAPS - 1; k >= 0; --k) s += (float)(acc[(size_t)k * B + b].dsum / d.n[k]);
+  out[b] = s;
+}
+
+// ---------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------
+static Gauss make_gauss() {
+  // gaussian(21, 7): exp(-(x-10)^2 / (2*7^2)) in double, stored as float, normalised in float
+  // (ADISTS.py:102-104 builds a float32 tensor and divides by its float32 sum)
+  Gauss g;
+  float s = 0.f;
+  float v[kWin];
+  for (int i = 0; i < kWin; ++i) v[i] = (float)exp(-(double)((i - 10) * (i - 10)) / (2.0 * 7.0 * 7.0));
+  // torch.sum of 21 floats: sequential order is within 1 ulp of any other; use double then round
+  double sd = 0.0;
+  for (int i = 0; i < kWin; ++i) sd += (double)v[i];
+  s = (float)sd;
+  for (int i = 0; i < kWin; ++i) g.g[i] = v[i] / s;
+  return g;
+}
+
+struct APlan {
+  // byte offsets into the workspace
+  size_t bufA, bufB, taps[5], img4x, img4y, part, q, ent, wgt, maps[NQA_NUM_TAPS][4], acc, total;
+  StageDesc sd;
+  EntDesc ed;
+  int h[NQA_NUM_TAPS], w[NQA_NUM_TAPS], c[NQA_NUM_TAPS];  // feature dims per tap (k=0 raw image)
+  int mh[NQA_NUM_TAPS], mw[NQA_NUM_TAPS];                  // map dims (1x1 for the global branch)
+  bool windowed[NQA_NUM_TAPS];
+  int ent_ppb[NQA_NUM_TAPS];
+};
+
+static APlan make_plan(int B, int H, int W, int prec) {
+  APlan p;
+  memset(&p, 0, sizeof(p));
+  const size_t esz = prec_elem_bytes(prec);
+  p.h[0] = H;
+  p.w[0] = W;
+  p.c[0] = 3;
+  int h = H, w = W;
+  for (int k = 1; k < 6; ++k) {
+    if (k > 1) {
+      h = (h + 1) / 2;
+      w = (w + 1) / 2;
+    }
+    p.h[k] = h;
+    p.w[k] = w;
+    p.c[k] = kChns[k];
+  }
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    const size_t o = off;
+    off += align_up(bytes, 256);
+    return o;
+  };
+  const size_t act = (size_t)2 * B * H * W * 64 * esz;
+  p.bufA = take(act);
+  p.bufB = take(act);
+  for (int k = 0; k < 5; ++k) p.taps[k] = take((size_t)2 * B * p.h[k + 1] * p.w[k + 1] * p.c[k + 1] * esz);
+  p.img4x = take((size_t)B * H * W * 4 * 4);
+  p.img4y = take((size_t)B * H * W * 4 * 4);
+  // statistics partials: stage 0 from the NCHW kernel, stages 1..5 from the NHWC kernel
+  long doff = 0;
+  int coff = 0;
+  for (int k = 0; k < 6; ++k) {
+    const int hw = p.h[k] * p.w[k];
+    const int ppb = k == 0 ? stats_nchw_ppb(hw) : stats_nhwc_ppb(p.c[k], prec);
+    p.sd.part_off[k] = doff;
+    p.sd.nblk[k] = cdiv(hw, ppb);
+    p.sd.hw[k] = hw;
+    p.sd.c[k] = p.c[k];
+    p.sd.coff[k] = coff;
+    doff += (long)B * p.sd.nblk[k] * p.c[k] * 5;
+    coff += p.c[k];
+  }
+  p.sd.nstage = 6;
+  p.sd.ctot = coff;
+  p.part = take((size_t)doff * 8);
+  p.q = take((size_t)8 * B * coff * 4);
+  long eoff = 0;
+  for (int k = 0; k < 6; ++k) {
+    const int hw = p.h[k] * p.w[k];
+    const int cpad = k == 0 ? 4 : p.c[k];
+    const int ppb = stats_nhwc_ppb(cpad, k == 0 ? NQA_PREC_F32 : prec);
+    p.ent_ppb[k] = ppb;
+    p.ed.part_off[k] = eoff;
+    p.ed.nblk[k] = cdiv(hw, ppb);
+    p.ed.c[k] = cpad;
+    p.ed.creal[k] = p.c[k];
+    p.ed.coff[k] = p.sd.coff[k];
+    eoff += (long)B * p.ed.nblk[k] * cpad;
+  }
+  p.ed.ctot = coff;
+  p.ent = take((size_t)eoff * 8);
+  p.wgt = take((size_t)B * coff * 4);
+  for (int k = 0; k < 6; ++k) {
+    p.windowed[k] = p.h[k] >= kWin && p.w[k] >= kWin;
+    p.mh[k] = p.windowed[k] ? p.h[k] - (kWin - 1) : 1;
+    p.mw[k] = p.windowed[k] ? p.w[k] - (kWin - 1) : 1;
+    for (int j = 0; j < 4; ++j) p.maps[k][j] = take((size_t)B * p.mh[k] * p.mw[k] * 4);
+  }
+  p.acc = take((size_t)6 * B * sizeof(ChainAcc));
+  p.total = off;
+  return p;
+}
+
+template <typename P>
+static int launch_entropy(const void *feat, int B, int HW, int C, int ppb, const float *invx, const float *sumx,
+                          int ctot, double *part, hipStream_t st) {
+  dim3 grid(cdiv(HW, ppb), B);
+  TimedLaunch t(NQA_K_ADISTS, st);
+  entropy_nhwc_kernel<P><<<grid, 256, 0, st>>>(reinterpret_cast<const typename P::T *>(feat), HW, C, ppb, invx, sumx,
+                                               ctot, part);
+  return check_launch("entropy");
+}
+
+template <typename P>
+static int launch_window(const void *fx, const void *fy, int B, int H, int W, int C, int creal, const float *q,
+                         int ctot, int coff, const float *wgt, const Gauss &g, float *gamma, float *tw, float *sw,
+                         hipStream_t st) {
+  const int Ho = H - (kWin - 1), Wo = W - (kWin - 1);
+  dim3 grid(cdiv(Wo, kTile), cdiv(Ho, kTile), B);
+  const size_t lds = (size_t)(2 * kHalo * kHalo + 5 * kHalo * kTile) * 16;  // 87.5 KB of the CU's 160 KB
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(adists_window_kernel<P>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      set_error("adists_window: cannot raise the dynamic LDS limit to %zu bytes", lds);
+      return NQA_E_LAUNCH;
+    }
+    attr_done = true;
+  }
+  TimedLaunch t(NQA_K_ADISTS, st);
+  adists_window_kernel<P><<<grid, 256, lds, st>>>(reinterpret_cast<const typename P::T *>(fx),
+                                                  reinterpret_cast<const typename P::T *>(fy), H, W, C, creal, q, B,
+                                                  ctot, coff, wgt, g, gamma, tw, sw);
+  return check_launch("adists_window");
+}
+
+}  // namespace nqa
 
 using namespace nqa;
 
 extern "C" {
 
 size_t nqa_adists_workspace_bytes(int B, int H, int W, int prec) {
-  (void)B; (void)H; (void)W; (void)prec;
-  return 0;
+  if (B <= 0 || H <= 0 || W <= 0) return 0;
+  return make_plan(B, H, W, prec).total;
 }
 
-int nqa_adists_forward(const float *, const float *, int, int, int, const void *, int, void *, size_t, float *,
-                       void *) {
-  set_error("adists_forward: not implemented in this build");
-  return NQA_E_SHAPE;
+int nqa_adists_forward(const float *x, const float *y, int B, int H, int W, const void *packed, int prec, void *ws,
+                       size_t ws_bytes, float *d_out, void *stream) {
+  if (!x || !y || !packed || !ws || !d_out) {
+    set_error("adists_forward: null pointer");
+    return NQA_E_ARG;
+  }
+  if (B <= 0 || H <= 0 || W <= 0 || (prec != NQA_PREC_F32 && prec != NQA_PREC_BF16 && prec != NQA_PREC_F16)) {
+    set_error("adists_forward: bad size or prec (B=%d H=%d W=%d prec=%d)", B, H, W, prec);
+    return NQA_E_ARG;
+  }
+  if ((long)H * W * 512 >= (1L << 31)) {
+    set_error("adists_forward: image too large");
+    return NQA_E_ARG;
+  }
+  const APlan p = make_plan(B, H, W, prec);
+  if (ws_bytes < p.total) {
+    set_error("adists_forward: workspace %zu < %zu bytes", ws_bytes, p.total);
+    return NQA_E_WORKSPACE;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  char *base = static_cast<char *>(ws);
+  const size_t esz = prec_elem_bytes(prec);
+  const int ctot = p.sd.ctot;
+  double *part = reinterpret_cast<double *>(base + p.part);
+  float *q = reinterpret_cast<float *>(base + p.q);
+  double *ent = reinterpret_cast<double *>(base + p.ent);
+  float *wgt = reinterpret_cast<float *>(base + p.wgt);
+  ChainAcc *acc = reinterpret_cast<ChainAcc *>(base + p.acc);
+  void *taps[5];
+  for (int k = 0; k < 5; ++k) taps[k] = base + p.taps[k];
+  int rc;
+
+  // ---- pyramids (x images [0,B), y images [B,2B)) with the global statistics per tap ----
+  if ((rc = stats_nchw(x, y, B, 3, H * W, part + p.sd.part_off[0], st))) return rc;
+  if ((rc = conv1_1(x, B, H, W, packed, prec, base + p.bufA, st))) return rc;
+  if ((rc = conv1_1(y, B, H, W, packed, prec, base + p.bufA + (size_t)B * H * W * 64 * esz, st))) return rc;
+  {
+    // same chaining as nqa_vgg_pyramid, taps kept
+    void *bufA = base + p.bufA, *bufB = base + p.bufB, *cur = bufA;
+    for (int layer = 1; layer < NQA_NUM_CONVS; ++layer) {
+      const ConvSpec &cs = kConvs[layer];
+      const int k = cs.stage;
+      void *dst = cs.last ? taps[k] : (cur == bufA ? bufB : bufA);
+      if ((rc = conv3x3(cur, 2 * B, p.h[k + 1], p.w[k + 1], layer, packed, prec, dst, st))) return rc;
+      cur = dst;
+      if (cs.last) {
+        if ((rc = stats_nhwc(cur, B, p.h[k + 1] * p.w[k + 1], cs.cout, prec, part + p.sd.part_off[k + 1], st)))
+          return rc;
+        if (k < 4) {
+          if ((rc = l2pool(cur, 2 * B, p.h[k + 1], p.w[k + 1], cs.cout, prec, bufA, st))) return rc;
+          cur = bufA;
+        }
+      }
+    }
+  }
+  // ---- per-channel scalars, stage-0 images as NHWC4, entropies, channel weights ----
+  {
+    dim3 grid(cdiv(ctot, 256), B);
+    TimedLaunch t(NQA_K_ADISTS, st);
+    adists_prep_kernel<<<grid, 256, 0, st>>>(part, p.sd, q, B);
+    if ((rc = check_launch("adists_prep"))) return rc;
+  }
+  float *img4x = reinterpret_cast<float *>(base + p.img4x), *img4y = reinterpret_cast<float *>(base + p.img4y);
+  {
+    dim3 grid(cdiv(H * W, 256), B);
+    TimedLaunch t(NQA_K_ADISTS, st);
+    nchw3_to_nhwc4_kernel<<<grid, 256, 0, st>>>(x, img4x, H * W);
+    nchw3_to_nhwc4_kernel<<<grid, 256, 0, st>>>(y, img4y, H * W);
+    if ((rc = check_launch("nchw3_to_nhwc4"))) return rc;
+  }
+  const size_t qst = (size_t)B * ctot;
+  // stage 0's q/wgt rows are indexed with channel < 3; the NHWC4 kernels read index 3 too, which
+  // is channel 0 of stage 1 in the concatenated vector -- harmless: its feature value is 0 (entropy
+  // term 0) and the window kernel masks c >= creal.
+  if ((rc = launch_entropy<PrecF32>(img4x, B, H * W, 4, p.ent_ppb[0], q + 0 * qst + p.sd.coff[0],
+                                    q + 2 * qst + p.sd.coff[0], ctot, ent + p.ed.part_off[0], st)))
+    return rc;
+  for (int k = 1; k < 6; ++k) {
+    const int hw = p.h[k] * p.w[k];
+    const float *invx = q + 0 * qst + p.sd.coff[k], *sumx = q + 2 * qst + p.sd.coff[k];
+    double *ep = ent + p.ed.part_off[k];
+    switch (prec) {
+      case NQA_PREC_F32: rc = launch_entropy<PrecF32>(taps[k - 1], B, hw, p.c[k], p.ent_ppb[k], invx, sumx, ctot, ep, st); break;
+      case NQA_PREC_BF16: rc = launch_entropy<PrecBF16>(taps[k - 1], B, hw, p.c[k], p.ent_ppb[k], invx, sumx, ctot, ep, st); break;
+      default: rc = launch_entropy<PrecF16>(taps[k - 1], B, hw, p.c[k], p.ent_ppb[k], invx, sumx, ctot, ep, st); break;
+    }
+    if (rc) return rc;
+  }
+  {
+    TimedLaunch t(NQA_K_ADISTS, st);
+    adists_weights_kernel<<<B, 256, 0, st>>>(ent, p.ed, wgt);
+    if ((rc = check_launch("adists_weights"))) return rc;
+  }
+  // ---- heavy pass: gamma / TW / SW maps per stage ----
+  static const Gauss gauss = make_gauss();
+  for (int k = 0; k < 6; ++k) {
+    float *gamma = reinterpret_cast<float *>(base + p.maps[k][0]);
+    float *tw = reinterpret_cast<float *>(base + p.maps[k][1]);
+    float *sw = reinterpret_cast<float *>(base + p.maps[k][2]);
+    if (!p.windowed[k]) {
+      TimedLaunch t(NQA_K_ADISTS, st);
+      adists_global_kernel<<<B, 256, 0, st>>>(q, B, ctot, p.sd.coff[k], p.c[k], wgt, gamma, tw, sw);
+      if ((rc = check_launch("adists_global"))) return rc;
+      continue;
+    }
+    if (k == 0) {
+      rc = launch_window<PrecF32>(img4x, img4y, B, H, W, 4, 3, q, ctot, 0, wgt, gauss, gamma, tw, sw, st);
+    } else {
+      const char *tx = static_cast<const char *>(taps[k - 1]);
+      const char *ty = tx + (size_t)B * p.h[k] * p.w[k] * p.c[k] * esz;
+      switch (prec) {
+        case NQA_PREC_F32: rc = launch_window<PrecF32>(tx, ty, B, p.h[k], p.w[k], p.c[k], p.c[k], q, ctot, p.sd.coff[k], wgt, gauss, gamma, tw, sw, st); break;
+        case NQA_PREC_BF16: rc = launch_window<PrecBF16>(tx, ty, B, p.h[k], p.w[k], p.c[k], p.c[k], q, ctot, p.sd.coff[k], wgt, gauss, gamma, tw, sw, st); break;
+        default: rc = launch_window<PrecF16>(tx, ty, B, p.h[k], p.w[k], p.c[k], p.c[k], q, ctot, p.sd.coff[k], wgt, gauss, gamma, tw, sw, st); break;
+      }
+    }
+    if (rc) return rc;
+  }
+  // ---- probability chain, coarse to fine ----
+  {
+    TimedLaunch t(NQA_K_ADISTS, st);
+    chain_init_kernel<<<cdiv(6 * B, 256), 256, 0, st>>>(acc, 6 * B);
+    // initial ps_prod = ones (ADISTS.py:75): a 1x1 map of 1 upsamples to the same constant
+    float *ones = reinterpret_cast<float *>(base + p.bufB);  // the ping-pong buffers are free now
+    ones_kernel<<<cdiv(B, 256), 256, 0, st>>>(ones, B);
+    const float *prev = ones;
+    int hp = 1, wp = 1;
+    for (int k = 5; k >= 0; --k) {
+      const float *gamma = reinterpret_cast<const float *>(base + p.maps[k][0]);
+      const float *tw = reinterpret_cast<const float *>(base + p.maps[k][1]);
+      const float *sw = reinterpret_cast<const float *>(base + p.maps[k][2]);
+      float *psprod = reinterpret_cast<float *>(base + p.maps[k][3]);
+      ChainAcc *a = acc + (size_t)k * B;
+      if (p.windowed[k]) {
+        const int n = p.mh[k] * p.mw[k];
+        dim3 grid(min(cdiv(n, 256), 1024), B);
+        chain_moments_kernel<<<grid, 256, 0, st>>>(gamma, n, a);
+        chain_psminmax_kernel<<<grid, 256, 0, st>>>(gamma, n, a);
+        chain_ppminmax_kernel<<<grid, 256, 0, st>>>(gamma, p.mh[k], p.mw[k], prev, hp, wp, a);
+        chain_final_kernel<<<grid, 256, 0, st>>>(gamma, p.mh[k], p.mw[k], prev, hp, wp, tw, sw, psprod, a);
+      } else {
+        chain_global_kernel<<<cdiv(B, 256), 256, 0, st>>>(gamma, prev, hp * wp, tw, sw, psprod, a, B);
+      }
+      prev = psprod;
+      hp = p.mh[k];
+      wp = p.mw[k];
+    }
+    DDesc dd;
+    for (int k = 0; k < 6; ++k) dd.n[k] = p.mh[k] * p.mw[k];
+    adists_d_kernel<<<cdiv(B, 256), 256, 0, st>>>(acc, dd, B, d_out);
+    if ((rc = check_launch("adists_chain"))) return rc;
+  }
+  return NQA_OK;
 }
 
 }  // extern "C"

@@ -201,3 +201,19 @@ def timing_collect():
     ms = (C.c_double * 5)()
     check(lib().nqa_timing_collect(n, ms))
     return {name: (n[i], ms[i]) for i, name in enumerate(_lib.K_NAMES)}
+
+
+def adists_forward(x: torch.Tensor, y: torch.Tensor, packed: torch.Tensor, prec, ws: Workspace | None = None):
+    """D (B,) float32 of ADISTS.forward (ADISTS.py:147-191); the caller returns 1-D or 1-mean(D)."""
+    p = prec_id(prec)
+    dev = _need_cuda(x, y, packed)
+    x, y = _f32c(x), _f32c(y)
+    if x.shape != y.shape or x.dim() != 4 or x.shape[1] != 3:
+        raise ValueError(f"expected two (B,3,H,W) tensors of equal shape, got {tuple(x.shape)} / {tuple(y.shape)}")
+    b, _, h, w = x.shape
+    d = torch.empty((b,), dtype=torch.float32, device=dev)
+    nbytes = lib().nqa_adists_workspace_bytes(b, h, w, p)
+    buf = (ws or Workspace()).get(nbytes, dev)
+    check(lib().nqa_adists_forward(ptr(x), ptr(y), b, h, w, ptr(packed), p, ptr(buf), buf.numel(), ptr(d),
+                                   stream_ptr(dev)))
+    return d

@@ -1,0 +1,60 @@
+"""A-DISTS on the HIP path against the golden vectors frozen from the imported reference."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+ADISTS_GOLD = sorted(glob.glob(os.path.join(GOLDEN, "adists_*.npz")))
+SCORE_TOL = {"f32": 1e-4, "f16": 1e-4, "bf16": 1e-3}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def packed(np_convs, dev):
+    from nerf_qa_amd import ops
+    return {p: ops.pack_vgg_weights(np_convs, p).to(dev) for p in ("f32", "f16", "bf16")}
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("path", ADISTS_GOLD, ids=[os.path.basename(p)[:-4] for p in ADISTS_GOLD])
+def test_adists_vs_golden(path, prec, packed, dev):
+    from nerf_qa_amd import ops, synth
+    g = np.load(path)
+    x, y = synth.frame_batch([int(s) for s in g["seeds"]], int(g["h"]), int(g["w"]), [str(k) for k in g["kinds"]])
+    d = ops.adists_forward(torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev), packed[prec], prec)
+    score = (1 - d).cpu().numpy()
+    err = np.abs(score - g["score"]).max()
+    print(f"\n{os.path.basename(path)} [{prec}] hip={score} ref={g['score']} |d|={err:.2e}")
+    assert err <= SCORE_TOL[prec]
+    loss = (1 - d.mean()).item()
+    assert abs(loss - float(g["loss"])) <= SCORE_TOL[prec]
+
+
+def test_adists_module_surface(dev):
+    import warnings
+    from nerf_qa_amd import synth
+    from nerf_qa_amd.ADISTS import ADISTS
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = ADISTS().to(dev).eval()
+    x, y = synth.frame_batch([3, 4], 64, 72)
+    x, y = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
+    s = m(x, y, as_loss=False)
+    assert s.shape == (2,)
+    assert abs(m(x, y).item() - s.mean().item()) < 1e-6
+    z = m(x, x, as_loss=False)
+    assert z.abs().max().item() < 5e-6
+    with pytest.raises(NotImplementedError):
+        m(x, y, as_map=True)
+    feats = m.forward_once(x)
+    assert [f.shape[1] for f in feats] == [3, 64, 128, 256, 512, 512]
