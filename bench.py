@@ -48,10 +48,23 @@ def conv_flops_per_image(h, w):
     return ig, 2 * 9 * 3 * 64 * h * w
 
 
+def host_cores():
+    """Cores this process may actually use: the cgroup CPU quota if there is one (the GPU box
+    shows 256 logical CPUs but grants a 16-core share), else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(h, w, budget_s=20.0):
     """The oracle (kind "port") on the host cores: frame-pairs/s on a bounded sample."""
     from oracle import dists_oracle
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     convs = dists_oracle.convs_from_numpy(synth.vgg16_weights(1234))
     ab = DISTS_alpha_beta()

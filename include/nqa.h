@@ -133,6 +133,13 @@ size_t nqa_adists_workspace_bytes(int B, int H, int W, int prec);
 int nqa_adists_forward(const float *x_nchw, const float *y_nchw, int B, int H, int W, const void *packed_w, int prec,
                        void *workspace, size_t workspace_bytes, float *d, void *stream);
 
+/* ---- tuning hook ------------------------------------------------------------------ */
+
+/* Block-tile choice of the implicit-GEMM conv: 0 = 4-wave tiles (128 ch x 128 px) on every
+ * layer, 1 = 8-wave 256 ch x 256 px tiles on layers with >= 256 output channels (default).
+ * Results are identical either way; this only exists so both can be timed in one process. */
+int nqa_set_conv_variant(int variant);
+
 /* ---- per-kernel timing (bench.py's roofline leg) -------------------------------- */
 
 /* When enabled, every launch of the conv / pool / stats kernels is bracketed by a

@@ -38,6 +38,7 @@ _SIGNATURES = {
     "nqa_dists_score": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "nqa_adists_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "nqa_adists_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _sz, _vp, _vp]),
+    "nqa_set_conv_variant": (_i, [_i]),
     "nqa_timing_enable": (_i, [_i]),
     "nqa_timing_collect": (_i, [C.POINTER(_i), C.POINTER(C.c_double)]),
 }

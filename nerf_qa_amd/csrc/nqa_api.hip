@@ -60,7 +60,7 @@ static size_t layer_bytes(int layer, int prec) {
   return align_up((size_t)c.cin * c.cout * 9 * prec_elem_bytes(prec), 256) + align_up((size_t)c.cout * 4, 256);
 }
 size_t layer_offset(int layer, int prec) {
-  size_t o = 0;
+  size_t o = kZeroPage;
   for (int l = 0; l < layer; ++l) o += layer_bytes(l, prec);
   return o;
 }
@@ -199,6 +199,15 @@ extern "C" {
 int nqa_version(void) { return NQA_VERSION; }
 const char *nqa_last_error(void) { return g_err; }
 
+int nqa_set_conv_variant(int variant) {
+  if (variant < 0 || variant > 1) {
+    set_error("set_conv_variant: unknown variant %d", variant);
+    return NQA_E_ARG;
+  }
+  set_conv_variant(variant);
+  return NQA_OK;
+}
+
 int nqa_timing_enable(int on) {
   g_timing = on != 0;
   g_used = 0;
@@ -248,7 +257,7 @@ int nqa_pack_vgg_weights(const float *const w_host[NQA_NUM_CONVS], const float *
   const int cpc = prec == NQA_PREC_F32 ? 4 : 8, kc = 4 * cpc;
   for (int l = 1; l < NQA_NUM_CONVS; ++l) {
     const ConvSpec &cs = kConvs[l];
-    const int bn = conv_bn(cs.cout), ncc = cs.cin / kc;
+    const int bn = 64, ncc = cs.cin / kc;
     char *dst = blob + layer_offset(l, prec);
     for (int ct = 0; ct < cs.cout / bn; ++ct)
       for (int cc = 0; cc < ncc; ++cc)

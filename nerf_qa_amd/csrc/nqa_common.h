@@ -87,12 +87,12 @@ static const ConvSpec kConvs[NQA_NUM_CONVS] = {
 static const int kChns[NQA_NUM_TAPS] = {3, 64, 128, 256, 512, 512};
 static const int kChnOff[NQA_NUM_TAPS] = {0, 3, 67, 195, 451, 963};
 
-// Cout tile of the implicit-GEMM kernel for a layer.
-static inline int conv_bn(int cout) { return cout >= 128 ? 128 : 64; }
-
-// Packed-blob offsets (bytes).  Layer 0: float w[27][64] (k = (ky*3+kx)*3+c) then float
-// bias[64].  Layers 1..12: tiles [cout/BN][cin/KC][9][BN] rows of 64 bytes (chunk c of
-// row n stored at position c ^ ((n>>2)&3)), then float bias[cout].
+// Packed-blob layout (bytes).  [0,256): zero page (source of out-of-image halo pixels).
+// Layer 0: float w[27][64] (k = (ky*3+kx)*3+c) then float bias[64].  Layers 1..12: tiles
+// [cout/64][cin/KC][9 taps][64 rows] of 64 bytes (chunk c of row n stored at position
+// c ^ ((n>>2)&3)), then float bias[cout].  The 64-channel granularity lets any block tile
+// that is a multiple of 64 channels stream whole sub-slabs.
+static constexpr size_t kZeroPage = 256;
 size_t layer_offset(int layer, int prec);
 size_t layer_bias_offset(int layer, int prec);
 
@@ -111,6 +111,7 @@ struct StageDesc {
 };
 
 // ---- host launchers shared between translation units ---------------------------------
+void set_conv_variant(int v);
 int conv1_1(const float *x, int n, int H, int W, const void *packed, int prec, void *out, hipStream_t st);
 int conv3x3(const void *in, int n, int H, int W, int layer, const void *packed, int prec, void *out, hipStream_t st);
 int l2pool(const void *in, int n, int H, int W, int C, int prec, void *out, hipStream_t st);

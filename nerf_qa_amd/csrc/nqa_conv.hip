@@ -10,7 +10,8 @@
 //                       contraction runs over (tap, cin).  A block stages one halo tile of
 //                       input pixels per 64-byte channel chunk in LDS and re-reads it for
 //                       all 9 taps; weights arrive pre-tiled and pre-swizzled
-//                       (nqa_pack_vgg_weights) one kernel row (3 taps) at a time.
+//                       (nqa_pack_vgg_weights) one kernel row (3 taps) at a time.  Staging is
+//                       LDS-DMA, double-buffered, one barrier per stage.
 //
 // LDS images are rows of 64 bytes (one pixel or one output channel, 4 chunks of 16 B).
 // Chunk c of row r sits at position c ^ ((r>>2)&3): the 16 lanes that ds_read_b128 serves
@@ -85,129 +86,155 @@ __global__ __launch_bounds__(256) void conv1_1_kernel(const float *__restrict__ 
 // ---------------------------------------------------------------------------------
 // implicit-GEMM conv, layers 1..12
 // ---------------------------------------------------------------------------------
-template <int BN, int TW>
+// Block tile = BN output channels x MP output pixels (a TH x TW patch of one image), split
+// over WAVES_N x WAVES_M waves, each owning WN_T x WM_T MFMA tiles of 32x32.
+// A "stage" is one kernel row (3 taps) of one 64-byte channel chunk: 3*BN weight rows.
+// Both LDS images are filled by LDS-DMA (global_load_lds_dwordx4: per-lane source
+// address, wave-linear destination), double-buffered, so the loop has ONE barrier per
+// stage: the barrier's vmcnt(0) retires stage s while stage s+1 is already in flight.
+// Out-of-image halo pixels are sourced from a zero page, which is what zero padding is.
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+template <int WAVES_N, int WAVES_M, int WN_T, int WM_T, int TW>
 struct ConvGeom {
-  static constexpr int MP = (BN == 128) ? 128 : 256;  // output pixels per block
+  static constexpr int THREADS = 64 * WAVES_N * WAVES_M;
+  static constexpr int BN = WAVES_N * WN_T * 32;      // output channels per block
+  static constexpr int NSUB = BN / 64;                // 64-channel weight sub-slabs
+  static constexpr int MP = WAVES_M * WM_T * 32;      // output pixels per block
   static constexpr int TH = MP / TW;                  // tile rows
   static constexpr int HW_ = TW + 2, HH_ = TH + 2;    // halo extent
   static constexpr int NQ = HW_ * HH_;                // halo pixels
-  static constexpr int A_BYTES = NQ * 64;
-  static constexpr int A_ITEMS = NQ * 4;
-  static constexpr int A_ROUNDS = (A_ITEMS + 255) / 256;
-  static constexpr int W_ROWS = 3 * BN;               // one kernel row of taps
-  static constexpr int W_BYTES = W_ROWS * 64;
-  static constexpr int W_ROUNDS = (W_ROWS * 4) / 256;
-  static constexpr int LDS_BYTES = A_BYTES + W_BYTES;
+  static constexpr int A_ITEMS = NQ * 4;              // 16-byte chunks
+  static constexpr int A_ITEMS_PAD = (A_ITEMS + 63) / 64 * 64;
+  static constexpr int A_BYTES = A_ITEMS_PAD * 16;
+  static constexpr int A_ROUNDS = (A_ITEMS_PAD + THREADS - 1) / THREADS;
+  static constexpr int SUB_STAGE_ITEMS = 3 * 64 * 4;  // one sub-slab, one kernel row: 12 KB
+  static constexpr int W_ITEMS = NSUB * SUB_STAGE_ITEMS;
+  static constexpr int W_BYTES = W_ITEMS * 16;
+  static constexpr int W_ROUNDS = W_ITEMS / THREADS;
+  static constexpr int LDS_BYTES = 2 * (A_BYTES + W_BYTES);
+  static_assert(BN % 64 == 0 && W_ITEMS % THREADS == 0 && MP % TW == 0, "bad conv geometry");
 };
 
-template <typename P, int BN, int TW>
-__global__ __launch_bounds__(256) void conv3x3_igemm_kernel(const typename P::T *__restrict__ in,
-                                                            const char *__restrict__ wpk,
-                                                            const float *__restrict__ bias,
-                                                            typename P::T *__restrict__ out, int H, int W, int Cin,
-                                                            int Cout, int tiles_x) {
+template <typename P, int WAVES_N, int WAVES_M, int WN_T, int WM_T, int TW>
+__global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void conv3x3_igemm_kernel(
+    const typename P::T *__restrict__ in, const char *__restrict__ wpk, const float *__restrict__ bias,
+    const char *__restrict__ zero_page, typename P::T *__restrict__ out, int H, int W, int Cin, int Cout,
+    int tiles_x) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the LDS-DMA builtin exists in the device pass only
   typedef typename P::T T;
-  typedef ConvGeom<BN, TW> G;
-  __shared__ __attribute__((aligned(16))) char smem[G::LDS_BYTES];
+  typedef ConvGeom<WAVES_N, WAVES_M, WN_T, WM_T, TW> G;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [A0][A1][W0][W1]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
   const int bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
   const int n = blockIdx.y, ct = blockIdx.z;
   const int x0 = bx * TW, y0 = by * G::TH;
-  const int wn = (BN == 128) ? (wave & 1) : 0;   // which 64 output channels of the tile
-  const int wm = (BN == 128) ? (wave >> 1) : wave;  // which 64 pixels of the tile
+  const int wn = wave % WAVES_N, wm = wave / WAVES_N;
   const int nCC = Cin / P::KC;
+  const int S = nCC * 3;
 
-  // ---- per-thread staging plan for the halo tile (constant across channel chunks) ----
-  int a_goff[G::A_ROUNDS];
+  // ---- LDS-DMA plan: halo tile ----
+  const char *a_src[G::A_ROUNDS];
+  int a_step[G::A_ROUNDS];
+  {
+    const char *in_img = reinterpret_cast<const char *>(in + (size_t)n * H * W * Cin);
 #pragma unroll
-  for (int r = 0; r < G::A_ROUNDS; ++r) {
-    const int i = tid + 256 * r;
-    int off = -2;
-    if (i < G::A_ITEMS) {
+    for (int r = 0; r < G::A_ROUNDS; ++r) {
+      const int i = r * G::THREADS + tid;
       const int q = i >> 2, c = (i & 3) ^ ((q >> 2) & 3);
       const int hy = q / G::HW_, hx = q - hy * G::HW_;
       const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-      off = ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? (gy * W + gx) * Cin + c * P::CPC : -1;
+      const bool ok = i < G::A_ITEMS && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      a_src[r] = ok ? in_img + ((size_t)(gy * W + gx) * Cin + c * P::CPC) * sizeof(T) : zero_page;
+      a_step[r] = ok ? 64 : 0;
     }
-    a_goff[r] = off;
   }
-  const T *in_img = in + (size_t)n * H * W * Cin;
+  // ---- LDS-DMA plan: weight rows (sub-slab j, item idx) ----
+  const unsigned sub_stride = (unsigned)nCC * 9u * 64u * 64u;  // bytes between 64-channel sub-slabs
+  const char *w_layer = wpk + (size_t)ct * G::NSUB * sub_stride;
+  unsigned w_goff[G::W_ROUNDS];
+#pragma unroll
+  for (int r = 0; r < G::W_ROUNDS; ++r) {
+    const int i = r * G::THREADS + tid;
+    w_goff[r] = (unsigned)(i / G::SUB_STAGE_ITEMS) * sub_stride + (unsigned)(i % G::SUB_STAGE_ITEMS) * 16u;
+  }
+  const int wave_base = wave * 64 * 16;  // this wave's 1 KB slot inside a round
+
+  auto issue = [&](int s) {
+    const int cc = s / 3;
+    char *wdst = smem + 2 * G::A_BYTES + (s & 1) * G::W_BYTES + wave_base;
+    const char *wsrc = w_layer + (size_t)s * (G::SUB_STAGE_ITEMS * 16);
+#pragma unroll
+    for (int r = 0; r < G::W_ROUNDS; ++r)
+      __builtin_amdgcn_global_load_lds(wsrc + w_goff[r], (lds_void_t *)(wdst + r * G::THREADS * 16), 16, 0, 0);
+    if (s - cc * 3 == 0) {
+      char *adst = smem + (cc & 1) * G::A_BYTES + wave_base;
+#pragma unroll
+      for (int r = 0; r < G::A_ROUNDS; ++r) {
+        if (r * G::THREADS + wave * 64 < G::A_ITEMS_PAD)  // wave-uniform
+          __builtin_amdgcn_global_load_lds(a_src[r] + cc * a_step[r], (lds_void_t *)(adst + r * G::THREADS * 16), 16,
+                                           0, 0);
+      }
+    }
+  };
 
   // ---- per-lane LDS read addresses ----
-  int w_base[2], w_sw[2];  // weight rows (MFMA rows = output channels)
+  int w_base[WN_T], w_sw[WN_T];  // weight rows (MFMA rows = output channels)
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = wn * 64 + i * 32 + l31;
-    w_base[i] = G::A_BYTES + row * 64;
-    w_sw[i] = (row >> 2) & 3;
+  for (int i = 0; i < WN_T; ++i) {
+    const int cib = (wn * WN_T + i) * 32 + l31;
+    const int r64 = cib & 63;
+    w_base[i] = 2 * G::A_BYTES + (cib >> 6) * (G::SUB_STAGE_ITEMS * 16) + r64 * 64;
+    w_sw[i] = (r64 >> 2) & 3;
   }
-  int q0[2];  // halo index of this lane's output pixel at tap (0,0)
+  int q0[WM_T];  // halo index of this lane's output pixel at tap (0,0)
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int m = (wm * 2 + j) * 32 + l31;
+  for (int j = 0; j < WM_T; ++j) {
+    const int m = (wm * WM_T + j) * 32 + l31;
     const int ty = m / TW, tx = m - ty * TW;
     q0[j] = ty * G::HW_ + tx;
   }
 
-  f32x16 acc[2][2];
+  f32x16 acc[WN_T][WM_T];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < WN_T; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < WM_T; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const u32x4 zero4 = {0u, 0u, 0u, 0u};
-  for (int cc = 0; cc < nCC; ++cc) {
-    __syncthreads();  // everyone is done reading the previous halo tile and weight rows
-    {
-      const T *src = in_img + cc * P::KC;
+  issue(0);
+  for (int s = 0; s < S; ++s) {
+    const int cc = s / 3, ky = s - cc * 3;
+    __syncthreads();  // retires this wave's DMA for stage s; every wave has finished stage s-1
+    if (s + 1 < S) issue(s + 1);
+    const char *abuf = smem + (cc & 1) * G::A_BYTES;
+    const char *wbuf = smem + (s & 1) * G::W_BYTES;
 #pragma unroll
-      for (int r = 0; r < G::A_ROUNDS; ++r) {
-        const int off = a_goff[r];
-        if (off != -2) {
-          u32x4 v = zero4;
-          if (off >= 0) v = *reinterpret_cast<const u32x4 *>(src + off);
-          *reinterpret_cast<u32x4 *>(smem + (tid + 256 * r) * 16) = v;
-        }
+    for (int kx = 0; kx < 3; ++kx) {
+      int p_base[WM_T], p_sw[WM_T];
+#pragma unroll
+      for (int j = 0; j < WM_T; ++j) {
+        const int q = q0[j] + ky * G::HW_ + kx;
+        p_base[j] = q * 64;
+        p_sw[j] = (q >> 2) & 3;
       }
-    }
-    const u32x4 *slab = reinterpret_cast<const u32x4 *>(wpk + (size_t)(ct * nCC + cc) * 9 * BN * 64);
-#pragma unroll 1
-    for (int ky = 0; ky < 3; ++ky) {
-      if (ky) __syncthreads();  // previous kernel row's weights fully consumed
 #pragma unroll
-      for (int r = 0; r < G::W_ROUNDS; ++r) {
-        const int i = tid + 256 * r;
-        reinterpret_cast<u32x4 *>(smem + G::A_BYTES)[i] = slab[ky * G::W_ROWS * 4 + i];
-      }
-      __syncthreads();
+      for (int ks = 0; ks < 2; ++ks) {
+        const int ch = 2 * ks + h;
+        u32x4 af[WN_T], bf[WM_T];
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        int p_base[2], p_sw[2];
+        for (int i = 0; i < WN_T; ++i)
+          af[i] = *reinterpret_cast<const u32x4 *>(wbuf + w_base[i] + kx * 4096 + ((ch ^ w_sw[i]) << 4));
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int q = q0[j] + ky * G::HW_ + kx;
-          p_base[j] = q * 64;
-          p_sw[j] = (q >> 2) & 3;
-        }
+        for (int j = 0; j < WM_T; ++j)
+          bf[j] = *reinterpret_cast<const u32x4 *>(abuf + p_base[j] + ((ch ^ p_sw[j]) << 4));
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const int ch = 2 * s + h;
-          u32x4 af[2], bf[2];
+        for (int i = 0; i < WN_T; ++i)
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
-            af[i] = *reinterpret_cast<const u32x4 *>(smem + w_base[i] + kx * BN * 64 + ((ch ^ w_sw[i]) << 4));
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            bf[j] = *reinterpret_cast<const u32x4 *>(smem + p_base[j] + ((ch ^ p_sw[j]) << 4));
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = P::mma(af[i], bf[j], acc[i][j]);
-        }
+          for (int j = 0; j < WM_T; ++j) acc[i][j] = P::mma(af[i], bf[j], acc[i][j]);
       }
     }
   }
@@ -215,18 +242,19 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(const typename P::T 
   // ---- epilogue: bias + ReLU, 4 consecutive output channels per lane per store ----
   // acc[i][j][r]: channel = 8*(r>>2) + 4*h + (r&3) of row tile i, pixel = lane&31 of column tile j.
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int m = (wm * 2 + j) * 32 + l31;
+  for (int j = 0; j < WM_T; ++j) {
+    const int m = (wm * WM_T + j) * 32 + l31;
     const int ty = m / TW, tx = m - ty * TW;
     const int gy = y0 + ty, gx = x0 + tx;
     if (gy < H && gx < W) {
-      T *o = out + ((size_t)(n * H + gy) * W + gx) * Cout + ct * BN + wn * 64 + 4 * h;
+      const int cbase = ct * G::BN + wn * WN_T * 32 + 4 * h;
+      T *o = out + ((size_t)(n * H + gy) * W + gx) * Cout + cbase;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < WN_T; ++i) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int co = i * 32 + 8 * g;
-          const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bias + ct * BN + wn * 64 + 4 * h + co);
+          const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bias + cbase + co);
           float v[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[i][j][4 * g + e] + b4[e], 0.f);
@@ -242,11 +270,15 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(const typename P::T 
       }
     }
   }
+#endif
 }
 
 // ---------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------
+static int g_conv_variant = 1;  // 0: 4-wave tiles everywhere; 1: 8-wave tiles where the layer is wide enough
+void set_conv_variant(int v) { g_conv_variant = v; }
+
 template <typename P>
 static int launch_conv1_1(const float *x, int n, int H, int W, const char *packed, void *out, hipStream_t st) {
   const float *w = reinterpret_cast<const float *>(packed + layer_offset(0, P::ID));
@@ -257,16 +289,25 @@ static int launch_conv1_1(const float *x, int n, int H, int W, const char *packe
   return check_launch("conv1_1");
 }
 
-template <typename P, int BN, int TW>
+template <typename P, int WAVES_N, int WAVES_M, int WN_T, int WM_T, int TW>
 static int launch_igemm(const void *in, int n, int H, int W, int cin, int cout, const char *wpk, const float *bias,
-                        void *out, hipStream_t st) {
-  typedef ConvGeom<BN, TW> G;
+                        const char *zero_page, void *out, hipStream_t st) {
+  typedef ConvGeom<WAVES_N, WAVES_M, WN_T, WM_T, TW> G;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_igemm_kernel<P, WAVES_N, WAVES_M, WN_T, WM_T, TW>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES) != hipSuccess) {
+      set_error("conv3x3_igemm: cannot raise the dynamic LDS limit to %d bytes", G::LDS_BYTES);
+      return NQA_E_LAUNCH;
+    }
+    attr_done = true;
+  }
   const int tiles_x = cdiv(W, TW), tiles_y = cdiv(H, G::TH);
-  dim3 grid(tiles_x * tiles_y, n, cout / BN);
+  dim3 grid(tiles_x * tiles_y, n, cout / G::BN);
   TimedLaunch t(NQA_K_CONV, st);
-  conv3x3_igemm_kernel<P, BN, TW><<<grid, 256, 0, st>>>(reinterpret_cast<const typename P::T *>(in), wpk, bias,
-                                                        reinterpret_cast<typename P::T *>(out), H, W, cin, cout,
-                                                        tiles_x);
+  conv3x3_igemm_kernel<P, WAVES_N, WAVES_M, WN_T, WM_T, TW><<<grid, G::THREADS, G::LDS_BYTES, st>>>(
+      reinterpret_cast<const typename P::T *>(in), wpk, bias, zero_page, reinterpret_cast<typename P::T *>(out), H, W,
+      cin, cout, tiles_x);
   return check_launch("conv3x3_igemm");
 }
 
@@ -275,13 +316,16 @@ static int launch_conv(const void *in, int n, int H, int W, int layer, const cha
   const ConvSpec &cs = kConvs[layer];
   const char *wpk = packed + layer_offset(layer, P::ID);
   const float *bias = reinterpret_cast<const float *>(packed + layer_bias_offset(layer, P::ID));
+  const char *zp = packed;  // the blob starts with a 256-byte zero page
   const bool narrow = W <= 16;  // 32-wide tiles would be half empty
-  if (conv_bn(cs.cout) == 128) {
-    return narrow ? launch_igemm<P, 128, 16>(in, n, H, W, cs.cin, cs.cout, wpk, bias, out, st)
-                  : launch_igemm<P, 128, 32>(in, n, H, W, cs.cin, cs.cout, wpk, bias, out, st);
-  }
-  return narrow ? launch_igemm<P, 64, 16>(in, n, H, W, cs.cin, cs.cout, wpk, bias, out, st)
-                : launch_igemm<P, 64, 32>(in, n, H, W, cs.cin, cs.cout, wpk, bias, out, st);
+  const bool big = g_conv_variant == 1;
+#define NQA_GO(WN, WM, TN, TM)                                                                               \
+  return narrow ? launch_igemm<P, WN, WM, TN, TM, 16>(in, n, H, W, cs.cin, cs.cout, wpk, bias, zp, out, st) \
+                : launch_igemm<P, WN, WM, TN, TM, 32>(in, n, H, W, cs.cin, cs.cout, wpk, bias, zp, out, st)
+  if (cs.cout == 64) { NQA_GO(1, 4, 2, 2); }                    // 64 ch x 256 px, 4 waves
+  if (cs.cout == 128 || !big) { NQA_GO(2, 2, 2, 2); }           // 128 ch x 128 px, 4 waves
+  NQA_GO(2, 4, 4, 2);                                           // 256 ch x 256 px, 8 waves
+#undef NQA_GO
 }
 
 int conv1_1(const float *x, int n, int H, int W, const void *packed, int prec, void *out, hipStream_t st) {

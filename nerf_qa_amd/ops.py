@@ -192,6 +192,10 @@ def dists_score(s1: torch.Tensor, s2: torch.Tensor, alpha: torch.Tensor, beta: t
     return out
 
 
+def set_conv_variant(v: int) -> None:
+    check(lib().nqa_set_conv_variant(int(v)))
+
+
 def timing_enable(on: bool) -> None:
     check(lib().nqa_timing_enable(1 if on else 0))
 

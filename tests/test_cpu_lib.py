@@ -36,7 +36,7 @@ def test_argument_errors(lib):
 
 def _unpack_layer(blob, off, cin, cout, dtype, cpc):
     """Invert the documented tile layout back to OIHW (numpy)."""
-    kc, bn = 4 * cpc, (128 if cout >= 128 else 64)
+    kc, bn = 4 * cpc, 64
     ncc = cin // kc
     n_el = cin * cout * 9
     raw = blob[off:off + n_el * dtype().itemsize].view(dtype).reshape(cout // bn, ncc, 9, bn, 4, cpc)
@@ -59,8 +59,9 @@ def test_pack_roundtrip(prec, np_convs, lib):
     # recompute the documented offsets
     esz = 4 if prec == "f32" else 2
     al = lambda v: (v + 255) // 256 * 256
-    off = al(27 * 64 * 4 + 64 * 4)
-    w0 = blob[:27 * 64 * 4].view(np.float32).reshape(9, 3, 64)
+    assert not blob[:256].any()  # zero page: the source of out-of-image halo pixels
+    off = 256 + al(27 * 64 * 4 + 64 * 4)
+    w0 = blob[256:256 + 27 * 64 * 4].view(np.float32).reshape(9, 3, 64)
     assert np.array_equal(w0, np_convs[0][0].reshape(64, 3, 9).transpose(2, 1, 0))
     for l in (1, 2, 7, 12):
         cin, cout = ops.CONV_CIN[l], ops.CONV_COUT[l]

@@ -39,7 +39,10 @@ def run(prec, B, H, W, iters=5):
 
 
 if __name__ == "__main__":
-    for prec in ("f16", "bf16", "f32"):
-        run(prec, 32, 256, 256)
-    run("f16", 4, 1080, 1920, iters=3)
-    run("f32", 2, 1080, 1920, iters=2)
+    for v in (0, 1):
+        print("== conv variant", v)
+        ops.set_conv_variant(v)
+        run("f16", 32, 256, 256)
+        run("f16", 4, 1080, 1920, iters=3)
+    run("bf16", 32, 256, 256)
+    run("f32", 32, 256, 256)
