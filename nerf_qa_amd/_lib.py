@@ -11,7 +11,7 @@ import os
 import torch  # noqa: F401  (loads the HIP runtime the library binds to; must come first)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnqa_hip.so")
+LIB_PATH = os.environ.get("NQA_LIB") or os.path.join(_HERE, "libnqa_hip.so")  # NQA_LIB: development builds only
 
 PREC_F32, PREC_BF16, PREC_F16 = 0, 1, 2
 PREC_NAMES = {"f32": PREC_F32, "fp32": PREC_F32, "bf16": PREC_BF16, "f16": PREC_F16, "fp16": PREC_F16}

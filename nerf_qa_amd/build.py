@@ -21,15 +21,20 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP source and link the shared library; returns its path."""
-    if not force and not _stale():
+def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str | None = None) -> str:
+    """Compile every HIP source and link the shared library; returns its path.
+
+    extra_flags/out build a development variant (e.g. -DNQA_ABLATE_NO_DMA for timing-only
+    ablations) next to the product library; NQA_LIB selects it at load time.
+    """
+    lib = out or LIB
+    if not force and not extra_flags and not _stale():
         return LIB
     objs = []
     procs = []
     for src in SOURCES:
-        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
-        cmd = [HIPCC, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        obj = os.path.join(CSRC, src.replace(".hip", ".o" if not out else "." + os.path.basename(out) + ".o"))
+        cmd = [HIPCC, *FLAGS, *extra_flags, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -44,10 +49,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
             print(out)
     if failed:
         raise RuntimeError("libnqa_hip.so: compilation failed")
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib]
     subprocess.run(cmd, check=True)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    flags = [a for a in sys.argv[1:] if a.startswith("-D")]
+    outs = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--out=")]
+    print(build(force="--force" in sys.argv, verbose=True, extra_flags=flags,
+                out=os.path.join(HERE, outs[0]) if outs else None))

@@ -89,10 +89,9 @@ __global__ __launch_bounds__(256) void conv1_1_kernel(const float *__restrict__ 
 // Block tile = BN output channels x MP output pixels (a TH x TW patch of one image), split
 // over WAVES_N x WAVES_M waves, each owning WN_T x WM_T MFMA tiles of 32x32.
 // A "stage" is one kernel row (3 taps) of one 64-byte channel chunk: 3*BN weight rows.
-// Both LDS images are filled by LDS-DMA (global_load_lds_dwordx4: per-lane source
-// address, wave-linear destination), double-buffered, so the loop has ONE barrier per
-// stage: the barrier's vmcnt(0) retires stage s while stage s+1 is already in flight.
-// Out-of-image halo pixels are sourced from a zero page, which is what zero padding is.
+// Both LDS images are filled by LDS-DMA (buffer_load_dwordx4 ... lds: per-lane source
+// offset, wave-linear destination), double-buffered, so the loop has ONE barrier per
+// stage: vmcnt(0) + barrier retires stage s while stage s+1 is already in flight.
 typedef __attribute__((address_space(3))) void lds_void_t;
 
 template <int WAVES_N, int WAVES_M, int WN_T, int WM_T, int TW>
@@ -119,8 +118,7 @@ struct ConvGeom {
 template <typename P, int WAVES_N, int WAVES_M, int WN_T, int WM_T, int TW>
 __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void conv3x3_igemm_kernel(
     const typename P::T *__restrict__ in, const char *__restrict__ wpk, const float *__restrict__ bias,
-    const char *__restrict__ zero_page, typename P::T *__restrict__ out, int H, int W, int Cin, int Cout,
-    int tiles_x) {
+    typename P::T *__restrict__ out, int H, int W, int Cin, int Cout, int tiles_x) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the LDS-DMA builtin exists in the device pass only
   typedef typename P::T T;
   typedef ConvGeom<WAVES_N, WAVES_M, WN_T, WM_T, TW> G;
@@ -135,25 +133,32 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void conv3x3_igemm_kernel(
   const int nCC = Cin / P::KC;
   const int S = nCC * 3;
 
-  // ---- LDS-DMA plan: halo tile ----
-  const char *a_src[G::A_ROUNDS];
-  int a_step[G::A_ROUNDS];
-  {
-    const char *in_img = reinterpret_cast<const char *>(in + (size_t)n * H * W * Cin);
+  // ---- LDS-DMA plan: halo tile.  Buffer loads with the image as the buffer: an out-of-image
+  // halo pixel gets an out-of-range offset, so the DMA transfers nothing for it (or zeros);
+  // those LDS cells are zeroed once below and stay zero -- that is the conv's zero padding.
+  const unsigned kOOB = 0x80000000u;
+  unsigned a_goff[G::A_ROUNDS];
 #pragma unroll
-    for (int r = 0; r < G::A_ROUNDS; ++r) {
-      const int i = r * G::THREADS + tid;
-      const int q = i >> 2, c = (i & 3) ^ ((q >> 2) & 3);
-      const int hy = q / G::HW_, hx = q - hy * G::HW_;
-      const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-      const bool ok = i < G::A_ITEMS && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-      a_src[r] = ok ? in_img + ((size_t)(gy * W + gx) * Cin + c * P::CPC) * sizeof(T) : zero_page;
-      a_step[r] = ok ? 64 : 0;
+  for (int r = 0; r < G::A_ROUNDS; ++r) {
+    const int i = r * G::THREADS + tid;
+    const int q = i >> 2, c = (i & 3) ^ ((q >> 2) & 3);
+    const int hy = q / G::HW_, hx = q - hy * G::HW_;
+    const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+    const bool ok = i < G::A_ITEMS && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+    a_goff[r] = ok ? (unsigned)(((gy * W + gx) * Cin + c * P::CPC) * (int)sizeof(T)) : kOOB;
+    if (!ok && i < G::A_ITEMS_PAD) {
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      *reinterpret_cast<u32x4 *>(smem + i * 16) = z;
+      *reinterpret_cast<u32x4 *>(smem + G::A_BYTES + i * 16) = z;
     }
   }
+  const unsigned img_bytes = (unsigned)H * (unsigned)W * (unsigned)Cin * (unsigned)sizeof(T);
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<T *>(in + (size_t)n * H * W * Cin), 0, img_bytes, 0x00020000);
   // ---- LDS-DMA plan: weight rows (sub-slab j, item idx) ----
   const unsigned sub_stride = (unsigned)nCC * 9u * 64u * 64u;  // bytes between 64-channel sub-slabs
-  const char *w_layer = wpk + (size_t)ct * G::NSUB * sub_stride;
+  const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char *>(wpk + (size_t)ct * G::NSUB * sub_stride), 0, G::NSUB * sub_stride, 0x00020000);
   unsigned w_goff[G::W_ROUNDS];
 #pragma unroll
   for (int r = 0; r < G::W_ROUNDS; ++r) {
@@ -162,23 +167,29 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void conv3x3_igemm_kernel(
   }
   const int wave_base = wave * 64 * 16;  // this wave's 1 KB slot inside a round
 
+  // hipcc does not count buffer-to-LDS DMA in its s_waitcnt bookkeeping (and with
+  // global_load_lds it degrades every LDS wait in the loop to lgkmcnt(0)), so the DMA is
+  // retired by hand: dma_wait() before the barrier that publishes a stage.
   auto issue = [&](int s) {
+#ifndef NQA_ABLATE_NO_DMA
     const int cc = s / 3;
     char *wdst = smem + 2 * G::A_BYTES + (s & 1) * G::W_BYTES + wave_base;
-    const char *wsrc = w_layer + (size_t)s * (G::SUB_STAGE_ITEMS * 16);
 #pragma unroll
     for (int r = 0; r < G::W_ROUNDS; ++r)
-      __builtin_amdgcn_global_load_lds(wsrc + w_goff[r], (lds_void_t *)(wdst + r * G::THREADS * 16), 16, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void_t *)(wdst + r * G::THREADS * 16), 16, w_goff[r],
+                                               s * (G::SUB_STAGE_ITEMS * 16), 0, 0);
     if (s - cc * 3 == 0) {
       char *adst = smem + (cc & 1) * G::A_BYTES + wave_base;
 #pragma unroll
       for (int r = 0; r < G::A_ROUNDS; ++r) {
         if (r * G::THREADS + wave * 64 < G::A_ITEMS_PAD)  // wave-uniform
-          __builtin_amdgcn_global_load_lds(a_src[r] + cc * a_step[r], (lds_void_t *)(adst + r * G::THREADS * 16), 16,
-                                           0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_void_t *)(adst + r * G::THREADS * 16), 16, a_goff[r],
+                                                   cc * 64, 0, 0);
       }
     }
+#endif
   };
+  auto dma_wait = [] { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
 
   // ---- per-lane LDS read addresses ----
   int w_base[WN_T], w_sw[WN_T];  // weight rows (MFMA rows = output channels)
@@ -208,34 +219,51 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void conv3x3_igemm_kernel(
   issue(0);
   for (int s = 0; s < S; ++s) {
     const int cc = s / 3, ky = s - cc * 3;
-    __syncthreads();  // retires this wave's DMA for stage s; every wave has finished stage s-1
+    dma_wait();       // this wave's DMA for stage s has landed
+    __syncthreads();  // ... and everyone's; every wave has also finished reading stage s-1
     if (s + 1 < S) issue(s + 1);
     const char *abuf = smem + (cc & 1) * G::A_BYTES;
     const char *wbuf = smem + (s & 1) * G::W_BYTES;
+    // six k-steps per stage (3 taps x 2 chunk pairs); fragments of step t+1 are read from LDS
+    // while the MFMAs of step t run (two register sets, static indices)
+    auto load_frags = [&](int t, u32x4(&af)[WN_T], u32x4(&bf)[WM_T]) {
+      const int kx = t >> 1, ch = 2 * (t & 1) + h;
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
-      int p_base[WM_T], p_sw[WM_T];
+      for (int i = 0; i < WN_T; ++i)
+        af[i] = *reinterpret_cast<const u32x4 *>(wbuf + w_base[i] + kx * 4096 + ((ch ^ w_sw[i]) << 4));
 #pragma unroll
       for (int j = 0; j < WM_T; ++j) {
         const int q = q0[j] + ky * G::HW_ + kx;
-        p_base[j] = q * 64;
-        p_sw[j] = (q >> 2) & 3;
+        bf[j] = *reinterpret_cast<const u32x4 *>(abuf + q * 64 + ((ch ^ ((q >> 2) & 3)) << 4));
       }
+    };
+    auto mma_all = [&](const u32x4(&af)[WN_T], const u32x4(&bf)[WM_T]) {
+#ifndef NQA_ABLATE_NO_MFMA
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const int ch = 2 * ks + h;
-        u32x4 af[WN_T], bf[WM_T];
+      for (int i = 0; i < WN_T; ++i)
 #pragma unroll
-        for (int i = 0; i < WN_T; ++i)
-          af[i] = *reinterpret_cast<const u32x4 *>(wbuf + w_base[i] + kx * 4096 + ((ch ^ w_sw[i]) << 4));
+        for (int j = 0; j < WM_T; ++j) acc[i][j] = P::mma(af[i], bf[j], acc[i][j]);
+#else
 #pragma unroll
-        for (int j = 0; j < WM_T; ++j)
-          bf[j] = *reinterpret_cast<const u32x4 *>(abuf + p_base[j] + ((ch ^ p_sw[j]) << 4));
+      for (int i = 0; i < WN_T; ++i) asm volatile("" ::"v"(af[i]));
 #pragma unroll
-        for (int i = 0; i < WN_T; ++i)
+      for (int j = 0; j < WM_T; ++j) asm volatile("" ::"v"(bf[j]));
+#endif
+    };
+    // sched_barrier(0) pins "reads of the next step, then MFMAs of this step": left alone,
+    // hipcc sinks every ds_read to just before its MFMA and waits lgkmcnt(0) each time
+    u32x4 afA[WN_T], bfA[WM_T], afB[WN_T], bfB[WM_T];
+    load_frags(0, afA, bfA);
 #pragma unroll
-          for (int j = 0; j < WM_T; ++j) acc[i][j] = P::mma(af[i], bf[j], acc[i][j]);
-      }
+    for (int t = 0; t < 6; t += 2) {
+      load_frags(t + 1, afB, bfB);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_all(afA, bfA);
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 2 < 6) load_frags(t + 2, afA, bfA);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_all(afB, bfB);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 
@@ -291,7 +319,7 @@ static int launch_conv1_1(const float *x, int n, int H, int W, const char *packe
 
 template <typename P, int WAVES_N, int WAVES_M, int WN_T, int WM_T, int TW>
 static int launch_igemm(const void *in, int n, int H, int W, int cin, int cout, const char *wpk, const float *bias,
-                        const char *zero_page, void *out, hipStream_t st) {
+                        void *out, hipStream_t st) {
   typedef ConvGeom<WAVES_N, WAVES_M, WN_T, WM_T, TW> G;
   static bool attr_done = false;
   if (!attr_done) {
@@ -306,8 +334,8 @@ static int launch_igemm(const void *in, int n, int H, int W, int cin, int cout, 
   dim3 grid(tiles_x * tiles_y, n, cout / G::BN);
   TimedLaunch t(NQA_K_CONV, st);
   conv3x3_igemm_kernel<P, WAVES_N, WAVES_M, WN_T, WM_T, TW><<<grid, G::THREADS, G::LDS_BYTES, st>>>(
-      reinterpret_cast<const typename P::T *>(in), wpk, bias, zero_page, reinterpret_cast<typename P::T *>(out), H, W,
-      cin, cout, tiles_x);
+      reinterpret_cast<const typename P::T *>(in), wpk, bias, reinterpret_cast<typename P::T *>(out), H, W, cin, cout,
+      tiles_x);
   return check_launch("conv3x3_igemm");
 }
 
@@ -316,12 +344,11 @@ static int launch_conv(const void *in, int n, int H, int W, int layer, const cha
   const ConvSpec &cs = kConvs[layer];
   const char *wpk = packed + layer_offset(layer, P::ID);
   const float *bias = reinterpret_cast<const float *>(packed + layer_bias_offset(layer, P::ID));
-  const char *zp = packed;  // the blob starts with a 256-byte zero page
   const bool narrow = W <= 16;  // 32-wide tiles would be half empty
   const bool big = g_conv_variant == 1;
 #define NQA_GO(WN, WM, TN, TM)                                                                               \
-  return narrow ? launch_igemm<P, WN, WM, TN, TM, 16>(in, n, H, W, cs.cin, cs.cout, wpk, bias, zp, out, st) \
-                : launch_igemm<P, WN, WM, TN, TM, 32>(in, n, H, W, cs.cin, cs.cout, wpk, bias, zp, out, st)
+  return narrow ? launch_igemm<P, WN, WM, TN, TM, 16>(in, n, H, W, cs.cin, cs.cout, wpk, bias, out, st) \
+                : launch_igemm<P, WN, WM, TN, TM, 32>(in, n, H, W, cs.cin, cs.cout, wpk, bias, out, st)
   if (cs.cout == 64) { NQA_GO(1, 4, 2, 2); }                    // 64 ch x 256 px, 4 waves
   if (cs.cout == 128 || !big) { NQA_GO(2, 2, 2, 2); }           // 128 ch x 128 px, 4 waves
   NQA_GO(2, 4, 4, 2);                                           // 256 ch x 256 px, 8 waves
