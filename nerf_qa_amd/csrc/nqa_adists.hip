@@ -559,9 +559,11 @@ static APlan make_plan(int B, int H, int W, int prec) {
   int coff = 0;
   for (int k = 0; k < 6; ++k) {
     const int hw = p.h[k] * p.w[k];
-    const int ppb = k == 0 ? stats_nchw_ppb(hw) : stats_nhwc_ppb(p.c[k], prec);
+    // taps 1..4 get their statistics inside the fused pool pass (items = pooled pixels)
+    const int units = (k >= 1 && k <= 4) ? ((p.h[k] + 1) / 2) * ((p.w[k] + 1) / 2) : hw;
+    const int ppb = k == 0 ? stats_nchw_ppb(hw) : stats_units_per_block(units, p.c[k], prec, B);
     p.sd.part_off[k] = doff;
-    p.sd.nblk[k] = cdiv(hw, ppb);
+    p.sd.nblk[k] = cdiv(units, ppb);
     p.sd.hw[k] = hw;
     p.sd.c[k] = p.c[k];
     p.sd.coff[k] = coff;
@@ -576,7 +578,7 @@ static APlan make_plan(int B, int H, int W, int prec) {
   for (int k = 0; k < 6; ++k) {
     const int hw = p.h[k] * p.w[k];
     const int cpad = k == 0 ? 4 : p.c[k];
-    const int ppb = stats_nhwc_ppb(cpad, k == 0 ? NQA_PREC_F32 : prec);
+    const int ppb = stats_units_per_block(hw, cpad, k == 0 ? NQA_PREC_F32 : prec, B);
     p.ent_ppb[k] = ppb;
     p.ed.part_off[k] = eoff;
     p.ed.nblk[k] = cdiv(hw, ppb);
@@ -689,11 +691,12 @@ int nqa_adists_forward(const float *x, const float *y, int B, int H, int W, cons
       if ((rc = conv3x3(cur, 2 * B, p.h[k + 1], p.w[k + 1], layer, packed, prec, dst, st))) return rc;
       cur = dst;
       if (cs.last) {
-        if ((rc = stats_nhwc(cur, B, p.h[k + 1] * p.w[k + 1], cs.cout, prec, part + p.sd.part_off[k + 1], st)))
-          return rc;
+        double *pk = part + p.sd.part_off[k + 1];
         if (k < 4) {
-          if ((rc = l2pool(cur, 2 * B, p.h[k + 1], p.w[k + 1], cs.cout, prec, bufA, st))) return rc;
+          if ((rc = pool_stats(cur, B, p.h[k + 1], p.w[k + 1], cs.cout, prec, bufA, pk, st))) return rc;
           cur = bufA;
+        } else if ((rc = stats_nhwc(cur, B, p.h[k + 1] * p.w[k + 1], cs.cout, prec, pk, st))) {
+          return rc;
         }
       }
     }

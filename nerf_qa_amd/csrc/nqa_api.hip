@@ -123,7 +123,9 @@ static size_t act_bytes(int n, int H, int W, int prec) {
 
 // Runs layers 1..12 and the four L2-pools on `n` images whose conv1_1 output sits in bufA.
 // Stage k's last conv writes into taps[k] when taps is given, else into the ping-pong pair.
-// on_tap(k, ptr, Hk, Wk, Ck) is called once that conv is enqueued.
+// on_tap(k, tap, Hk, Wk, Ck, pool_dst) is called once that conv is enqueued; pool_dst is where
+// the stage's L2-pool output must go (null after stage 5).  It returns 1 if it pooled the tap
+// itself (the fused pool+statistics pass), 0 to have the plain L2-pool run, <0 on error.
 template <typename F>
 static int run_stages(void *bufA, void *bufB, int n, int H, int W, const void *packed, int prec, void *const *taps,
                       F on_tap, hipStream_t st) {
@@ -137,10 +139,10 @@ static int run_stages(void *bufA, void *bufB, int n, int H, int W, const void *p
     if ((rc = conv3x3(cur, n, d.h[k], d.w[k], layer, packed, prec, dst, st))) return rc;
     cur = dst;
     if (cs.last) {
-      if ((rc = on_tap(k, cur, d.h[k], d.w[k], cs.cout))) return rc;
+      void *pdst = k < 4 ? ((cur == bufA) ? bufB : bufA) : nullptr;
+      if ((rc = on_tap(k, cur, d.h[k], d.w[k], cs.cout, pdst)) < 0) return rc;
       if (k < 4) {
-        void *pdst = (cur == bufA) ? bufB : bufA;
-        if ((rc = l2pool(cur, n, d.h[k], d.w[k], cs.cout, prec, pdst, st))) return rc;
+        if (rc == 0 && (rc = l2pool(cur, n, d.h[k], d.w[k], cs.cout, prec, pdst, st))) return rc;
         cur = pdst;
       }
     }
@@ -168,16 +170,19 @@ struct StatsPlan {
   StageDesc d;
   size_t doubles;
 };
-static StatsPlan stats_plan(int B, const int *C, const int *HW, int nstage, int prec, bool stage0_nchw_only) {
+// `units[k]`: loop items of stage k's statistics pass -- pixels, or output pixels where the fused
+// pool+statistics kernel is used (null: every stage runs the NCHW plane kernel over HW[k]).
+static StatsPlan stats_plan(int B, const int *C, const int *HW, const int *units, int nstage, int prec) {
   StatsPlan p;
   memset(&p, 0, sizeof(p));
   long off = 0;
   int coff = 0;
   for (int k = 0; k < nstage; ++k) {
-    const bool nchw = stage0_nchw_only ? (k == 0) : true;
-    const int ppb = nchw ? stats_nchw_ppb(HW[k]) : stats_nhwc_ppb(C[k], prec);
+    const bool nchw = !units || k == 0;
+    const int n_units = nchw ? HW[k] : units[k];
+    const int ppb = nchw ? stats_nchw_ppb(HW[k]) : stats_units_per_block(n_units, C[k], prec, B);
     p.d.part_off[k] = off;
-    p.d.nblk[k] = cdiv(HW[k], ppb);
+    p.d.nblk[k] = cdiv(n_units, ppb);
     p.d.hw[k] = HW[k];
     p.d.c[k] = C[k];
     p.d.coff[k] = coff;
@@ -325,17 +330,24 @@ int nqa_nhwc_to_nchw_f32(const void *in, int n, int H, int W, int C, int prec, f
   return nhwc_to_nchw(in, n, H * W, C, prec, out, static_cast<hipStream_t>(stream));
 }
 
-size_t nqa_workspace_bytes(int n_images, int H, int W, int prec) {
-  if (n_images <= 0 || H <= 0 || W <= 0) return 0;
+// Statistics plan of the fused DISTS path: stage 0 from the raw images (NCHW kernel), taps 1..4
+// inside the fused pool+statistics pass (items = pooled pixels), tap 5 by the plain NHWC pass.
+static StatsPlan dists_stats_plan(int B, int H, int W, int prec) {
   const PyrDims d = pyr_dims(H, W);
-  int C[6], HW[6];
+  int C[6], HW[6], units[6];
   C[0] = 3;
-  HW[0] = H * W;
+  HW[0] = units[0] = H * W;
   for (int k = 0; k < 5; ++k) {
     C[k + 1] = kChns[k + 1];
     HW[k + 1] = d.h[k] * d.w[k];
+    units[k + 1] = k < 4 ? d.h[k + 1] * d.w[k + 1] : HW[k + 1];
   }
-  const StatsPlan p = stats_plan((n_images + 1) / 2, C, HW, 6, prec, true);
+  return stats_plan(B, C, HW, units, 6, prec);
+}
+
+size_t nqa_workspace_bytes(int n_images, int H, int W, int prec) {
+  if (n_images <= 0 || H <= 0 || W <= 0) return 0;
+  const StatsPlan p = dists_stats_plan((n_images + 1) / 2, H, W, prec);
   return 2 * act_bytes(n_images, H, W, prec) + align_up(p.doubles * 8, 256);
 }
 
@@ -360,7 +372,7 @@ int nqa_vgg_pyramid(const float *x, int n, int H, int W, const void *packed, int
   char *bufA = static_cast<char *>(ws), *bufB = bufA + ab;
   int rc;
   if ((rc = conv1_1(x, n, H, W, packed, prec, bufA, st))) return rc;
-  return run_stages(bufA, bufB, n, H, W, packed, prec, taps, [](int, void *, int, int, int) { return 0; }, st);
+  return run_stages(bufA, bufB, n, H, W, packed, prec, taps, [](int, void *, int, int, int, void *) { return 0; }, st);
 }
 
 int nqa_dists_forward(const float *x, const float *y, int B, int H, int W, const void *packed, int prec, void *ws,
@@ -380,15 +392,7 @@ int nqa_dists_forward(const float *x, const float *y, int B, int H, int W, const
   const size_t ab = act_bytes(n, H, W, prec);
   char *bufA = static_cast<char *>(ws), *bufB = bufA + ab;
   double *part = reinterpret_cast<double *>(bufB + ab);
-  const PyrDims d = pyr_dims(H, W);
-  int C[6], HW[6];
-  C[0] = 3;
-  HW[0] = H * W;
-  for (int k = 0; k < 5; ++k) {
-    C[k + 1] = kChns[k + 1];
-    HW[k + 1] = d.h[k] * d.w[k];
-  }
-  const StatsPlan p = stats_plan(B, C, HW, 6, prec, true);
+  const StatsPlan p = dists_stats_plan(B, H, W, prec);
   int rc;
   // feature 0 is the raw image (DISTS_pt.py:103): statistics straight from the inputs
   if ((rc = stats_nchw(x, y, B, 3, H * W, part + p.d.part_off[0], st))) return rc;
@@ -397,8 +401,11 @@ int nqa_dists_forward(const float *x, const float *y, int B, int H, int W, const
   if ((rc = conv1_1(y, B, H, W, packed, prec, bufA + (size_t)B * H * W * 64 * prec_elem_bytes(prec), st))) return rc;
   rc = run_stages(
       bufA, bufB, n, H, W, packed, prec, nullptr,
-      [&](int k, void *tap, int hk, int wk, int ck) {
-        return stats_nhwc(tap, B, hk * wk, ck, prec, part + p.d.part_off[k + 1], st);
+      [&](int k, void *tap, int hk, int wk, int ck, void *pool_dst) {
+        double *pk = part + p.d.part_off[k + 1];
+        if (!pool_dst) return stats_nhwc(tap, B, hk * wk, ck, prec, pk, st);
+        const int rc2 = pool_stats(tap, B, hk, wk, ck, prec, pool_dst, pk, st);
+        return rc2 ? rc2 : 1;
       },
       st);
   if (rc) return rc;
@@ -410,7 +417,7 @@ size_t nqa_stats_scratch_bytes(int B, const int C[NQA_NUM_TAPS], const int Hk[NQ
   if (B <= 0 || !C || !Hk || !Wk) return 0;
   int HW[6];
   for (int k = 0; k < 6; ++k) HW[k] = Hk[k] * Wk[k];
-  return align_up(stats_plan(B, C, HW, 6, NQA_PREC_F32, false).doubles * 8, 256);
+  return align_up(stats_plan(B, C, HW, nullptr, 6, NQA_PREC_F32).doubles * 8, 256);
 }
 
 int nqa_dists_stats_nchw(const float *const fx[NQA_NUM_TAPS], const float *const fy[NQA_NUM_TAPS], int B,
@@ -428,7 +435,7 @@ int nqa_dists_stats_nchw(const float *const fx[NQA_NUM_TAPS], const float *const
     }
     HW[k] = Hk[k] * Wk[k];
   }
-  const StatsPlan p = stats_plan(B, C, HW, 6, NQA_PREC_F32, false);
+  const StatsPlan p = stats_plan(B, C, HW, nullptr, 6, NQA_PREC_F32);
   if (scratch_bytes < p.doubles * 8) {
     set_error("dists_stats_nchw: scratch %zu < %zu bytes", scratch_bytes, p.doubles * 8);
     return NQA_E_WORKSPACE;

@@ -115,8 +115,9 @@ void set_conv_variant(int v);
 int conv1_1(const float *x, int n, int H, int W, const void *packed, int prec, void *out, hipStream_t st);
 int conv3x3(const void *in, int n, int H, int W, int layer, const void *packed, int prec, void *out, hipStream_t st);
 int l2pool(const void *in, int n, int H, int W, int C, int prec, void *out, hipStream_t st);
-int stats_nhwc_ppb(int C, int prec);
+int stats_units_per_block(int units, int C, int prec, int B);
 int stats_nchw_ppb(int HW);
+int pool_stats(const void *feat, int B, int H, int W, int C, int prec, void *pooled, double *part, hipStream_t st);
 int stats_nhwc(const void *feat, int B, int HW, int C, int prec, double *part, hipStream_t st);
 int stats_nchw(const float *fx, const float *fy, int B, int C, int HW, double *part, hipStream_t st);
 int finalize(const double *part, const StageDesc &d, int B, float *s1, float *s2, hipStream_t st);

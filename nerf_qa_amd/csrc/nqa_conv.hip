@@ -29,11 +29,18 @@ __global__ __launch_bounds__(256) void conv1_1_kernel(const float *__restrict__ 
                                                       const float *__restrict__ bias,
                                                       typename P::T *__restrict__ out, int H, int W) {
   typedef typename P::T T;
+  // One thread per output pixel (weights are wave-uniform -> scalar operands of the FMAs).  The
+  // 64 channels of 256 consecutive pixels are contiguous in NHWC, so results go through an LDS
+  // tile and leave as fully coalesced 16-byte stores, 128 bytes of channels per pass.
+  constexpr int HC = 128 / (int)sizeof(T);  // channels per pass: 64 (16-bit) or 32 (f32)
+  constexpr int PITCH = 128 + 16;           // row pitch in bytes; +16 spreads ds_write_b128 over the banks
+  __shared__ __attribute__((aligned(16))) char tile[256 * PITCH];
   const int HW = H * W;
-  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const int tid = threadIdx.x;
+  const int pix0 = blockIdx.x * 256, pix = pix0 + tid;
   const int n = blockIdx.y;
-  if (pix >= HW) return;
-  const int py = pix / W, px = pix - py * W;
+  const bool live = pix < HW;
+  const int py = live ? pix / W : 0, px = live ? pix - py * W : 0;
   const float mean[3] = {0.485f, 0.456f, 0.406f};
   const float sd[3] = {0.229f, 0.224f, 0.225f};
   float in[27];
@@ -43,7 +50,7 @@ __global__ __launch_bounds__(256) void conv1_1_kernel(const float *__restrict__ 
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
       const int gy = py + ky - 1, gx = px + kx - 1;
-      const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      const bool ok = live && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         float v = 0.f;
@@ -52,34 +59,49 @@ __global__ __launch_bounds__(256) void conv1_1_kernel(const float *__restrict__ 
       }
     }
   }
-  T *o = out + ((size_t)n * HW + pix) * 64;
-  // 4 groups of 16 output channels keeps the accumulators + inputs under 64 VGPRs.
+  char *o = reinterpret_cast<char *>(out + ((size_t)n * HW + pix0) * 64);
+  const int npix = min(256, HW - pix0);
 #pragma unroll 1
-  for (int g = 0; g < 4; ++g) {
-    float acc[16];
+  for (int half = 0; half < 64 / HC; ++half) {
+    // groups of 16 output channels keep accumulators + inputs under 64 VGPRs
+#pragma unroll 1
+    for (int g = 0; g < HC / 16; ++g) {
+      const int c0 = half * HC + g * 16;
+      float acc[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) acc[j] = bias[g * 16 + j];
+      for (int j = 0; j < 16; ++j) acc[j] = bias[c0 + j];
 #pragma unroll
-    for (int k = 0; k < 27; ++k) {
+      for (int k = 0; k < 27; ++k) {
 #pragma unroll
-      for (int j = 0; j < 16; ++j) acc[j] = fmaf(in[k], w[k * 64 + g * 16 + j], acc[j]);
-    }
-    if constexpr (sizeof(T) == 4) {
-#pragma unroll
-      for (int j = 0; j < 16; j += 4) {
-        f32x4 v = {fmaxf(acc[j], 0.f), fmaxf(acc[j + 1], 0.f), fmaxf(acc[j + 2], 0.f), fmaxf(acc[j + 3], 0.f)};
-        *reinterpret_cast<f32x4 *>(o + g * 16 + j) = v;
+        for (int j = 0; j < 16; ++j) acc[j] = fmaf(in[k], w[k * 64 + c0 + j], acc[j]);
       }
-    } else {
-      typedef __attribute__((ext_vector_type(8))) T t8;
+      T *row = reinterpret_cast<T *>(tile + tid * PITCH) + g * 16;
+      if constexpr (sizeof(T) == 4) {
 #pragma unroll
-      for (int j = 0; j < 16; j += 8) {
-        t8 v;
+        for (int j = 0; j < 16; j += 4) {
+          f32x4 v = {fmaxf(acc[j], 0.f), fmaxf(acc[j + 1], 0.f), fmaxf(acc[j + 2], 0.f), fmaxf(acc[j + 3], 0.f)};
+          *reinterpret_cast<f32x4 *>(row + j) = v;
+        }
+      } else {
+        typedef __attribute__((ext_vector_type(8))) T t8;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = P::from_f(fmaxf(acc[j + e], 0.f));
-        *reinterpret_cast<t8 *>(o + g * 16 + j) = v;
+        for (int j = 0; j < 16; j += 8) {
+          t8 v;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = P::from_f(fmaxf(acc[j + e], 0.f));
+          *reinterpret_cast<t8 *>(row + j) = v;
+        }
       }
     }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int i = r * 256 + tid, p = i >> 3, ch = i & 7;
+      if (p < npix)
+        *reinterpret_cast<u32x4 *>(o + (size_t)p * 64 * sizeof(T) + half * 128 + ch * 16) =
+            *reinterpret_cast<const u32x4 *>(tile + p * PITCH + ch * 16);
+    }
+    if (half + 1 < 64 / HC) __syncthreads();
   }
 }
 

@@ -8,10 +8,9 @@
 //   finalize_kernel      mean / variance / covariance -> S1, S2 (DISTS_pt.py:134,141)
 //   score_kernel         alpha/beta weighted sum -> 1 - (dist1+dist2) (DISTS_pt.py:127-144)
 //
-// Statistics are accumulated in float64 end to end.  The reference takes the variance
-// by a second pass over (f - mean); one pass over sum(f^2) in fp32 would lose digits at
-// 2 M pixels, while fp64 sums of exactly-representable fp32 products keep ~16 digits and
-// let every feature byte be read once.  FP64 FMA is cheap next to the HBM stream here.
+// Statistics: per-thread shifted fp32 moments, fp64 from the block reduction on (see
+// ShiftedMoments); the NCHW plane kernel (3-channel raw image, forward_from_feats) is fp64
+// throughout.
 #include "nqa_common.h"
 
 namespace nqa {
@@ -60,6 +59,148 @@ __global__ __launch_bounds__(256) void l2pool_kernel(const typename P::T *__rest
 }
 
 // ---------------------------------------------------------------------------------
+// Statistics accumulation.  The reference takes the variance by a second pass over (f - mean)
+// (DISTS_pt.py:137-138); a one-pass sum of f^2 in fp32 would cancel catastrophically for a
+// channel whose spread is small next to its mean.  Each thread therefore accumulates SHIFTED
+// moments in fp32 -- sum(f-p), sum((f-p)^2), sum((fx-px)(fy-py)) with the pivot p = the
+// thread's first sample of that channel, so the sums are of the order of the variance -- and
+// converts them to raw fp64 sums once, at the end; block partials and the final combine are
+// fp64.  Every feature byte is read once and the error stays relative to the variance.
+template <int N>
+struct ShiftedMoments {
+  float px[N], py[N];            // pivots
+  float s1x[N], s1y[N], s2x[N], s2y[N], sxy[N];
+  int n;
+  __device__ inline void init() {
+    n = 0;
+#pragma unroll
+    for (int e = 0; e < N; ++e) px[e] = py[e] = s1x[e] = s1y[e] = s2x[e] = s2y[e] = sxy[e] = 0.f;
+  }
+  __device__ inline void add(int e, float x, float y) {
+    const float dx = x - px[e], dy = y - py[e];
+    s1x[e] += dx;
+    s1y[e] += dy;
+    s2x[e] = fmaf(dx, dx, s2x[e]);
+    s2y[e] = fmaf(dy, dy, s2y[e]);
+    sxy[e] = fmaf(dx, dy, sxy[e]);
+  }
+  // raw sum s of channel e, s = {sum x, sum y, sum x^2, sum y^2, sum xy}
+  __device__ inline double raw(int e, int s) const {
+    const double p = px[e], q = py[e], nn = n, ax = s1x[e], ay = s1y[e];
+    switch (s) {
+      case 0: return ax + nn * p;
+      case 1: return ay + nn * q;
+      case 2: return (double)s2x[e] + 2.0 * p * ax + nn * p * p;
+      case 3: return (double)s2y[e] + 2.0 * q * ay + nn * q * q;
+      default: return (double)sxy[e] + q * ax + p * ay + nn * p * q;
+    }
+  }
+};
+
+// Block reduction of the per-thread raw sums over the pixel lanes -> part[(b*nblk+blk)*C*5 ...].
+template <int CPC>
+__device__ inline void reduce_store(const ShiftedMoments<CPC> &m, double *red, int tid, int G, int PL, int C,
+                                    double *dst) {
+#pragma unroll
+  for (int s = 0; s < 5; ++s) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < CPC; ++e) red[tid * CPC + e] = m.raw(e, s);
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+      const int cg = c / CPC, ce = c % CPC;
+      double sum = 0.0;
+      for (int q = 0; q < PL; ++q) sum += red[(q * G + cg) * CPC + ce];
+      dst[(size_t)c * 5 + s] = sum;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// L2-pool and the five statistics sums of one tapped map in ONE pass over it.  A block owns a
+// strip of OUTPUT pixels of image pair b (x image b, y image B+b); a thread owns one 16-byte
+// channel group and walks the strip.  For each output pixel it loads the 3x3 window of x and
+// of y, writes both pooled pixels, and adds the window's lower-right 2x2 (input pixels
+// (2oy..2oy+1, 2ox..2ox+1), each owned by exactly one output pixel) to the sums.
+template <typename P>
+__global__ __launch_bounds__(256) void pool_stats_kernel(const typename P::T *__restrict__ feat,
+                                                         typename P::T *__restrict__ pooled, int B, int H, int W,
+                                                         int C, int Ho, int Wo, int units_per_block,
+                                                         double *__restrict__ part) {
+  typedef typename P::T T;
+  typedef __attribute__((ext_vector_type(P::CPC))) T tvec;
+  __shared__ double red[256 * P::CPC];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
+  const int G = C / P::CPC, PL = 256 / G;
+  const int g = tid % G, pl = tid / G;
+  const int HoWo = Ho * Wo;
+  const int u_begin = blk * units_per_block;
+  const int u_end = min(HoWo, u_begin + units_per_block);
+  const T *fx = feat + (size_t)b * H * W * C + g * P::CPC;
+  const T *fy = feat + (size_t)(B + b) * H * W * C + g * P::CPC;
+  T *ox_ = pooled + (size_t)b * HoWo * C + g * P::CPC;
+  T *oy_ = pooled + (size_t)(B + b) * HoWo * C + g * P::CPC;
+  ShiftedMoments<P::CPC> m;
+  m.init();
+  if (u_begin + pl < u_end) {  // pivot = this thread's first owned sample (the window centre, always in range)
+    const int u = u_begin + pl, oy = u / Wo, ox = u - oy * Wo;
+    const size_t o = ((size_t)(2 * oy) * W + 2 * ox) * C;
+    const tvec vx = *reinterpret_cast<const tvec *>(fx + o), vy = *reinterpret_cast<const tvec *>(fy + o);
+#pragma unroll
+    for (int e = 0; e < P::CPC; ++e) {
+      m.px[e] = P::to_f(vx[e]);
+      m.py[e] = P::to_f(vy[e]);
+    }
+  }
+  for (int u = u_begin + pl; u < u_end; u += PL) {
+    const int oy = u / Wo, ox = u - oy * Wo;
+    // All 18 loads go out unconditionally from clamped coordinates, back to back (a branch per
+    // tap would serialise them into 9 round trips); an out-of-image tap is then zeroed for the
+    // pool (zero padding) and skipped by the sums.
+    tvec vx[9], vy[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int cy = min(max(2 * oy - 1 + t / 3, 0), H - 1), cx = min(max(2 * ox - 1 + t % 3, 0), W - 1);
+      const size_t o = ((size_t)cy * W + cx) * C;
+      vx[t] = *reinterpret_cast<const tvec *>(fx + o);
+      vy[t] = *reinterpret_cast<const tvec *>(fy + o);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // keep the 18 loads ahead of all the arithmetic
+    float px[P::CPC], py[P::CPC];
+#pragma unroll
+    for (int e = 0; e < P::CPC; ++e) px[e] = py[e] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int dy = t / 3, dx = t % 3;
+      const int iy = 2 * oy - 1 + dy, ix = 2 * ox - 1 + dx;
+      const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      const float wgt = ok ? ((dy == 1) ? 0.5f : 0.25f) * ((dx == 1) ? 0.5f : 0.25f) : 0.f;
+      if (dy >= 1 && dx >= 1 && ok) m.n += 1;
+#pragma unroll
+      for (int e = 0; e < P::CPC; ++e) {
+        const float x = P::to_f(vx[t][e]), y = P::to_f(vy[t][e]);
+        px[e] = fmaf(x * x, wgt, px[e]);
+        py[e] = fmaf(y * y, wgt, py[e]);
+        if (dy >= 1 && dx >= 1) {
+          // an out-of-image owned tap is replaced by the pivot: it adds exactly 0 to every sum
+          m.add(e, ok ? x : m.px[e], ok ? y : m.py[e]);
+        }
+      }
+    }
+    tvec qx, qy;
+#pragma unroll
+    for (int e = 0; e < P::CPC; ++e) {
+      qx[e] = P::from_f(sqrtf(px[e] + 1e-12f));
+      qy[e] = P::from_f(sqrtf(py[e] + 1e-12f));
+    }
+    *reinterpret_cast<tvec *>(ox_ + (size_t)u * C) = qx;
+    *reinterpret_cast<tvec *>(oy_ + (size_t)u * C) = qy;
+  }
+  reduce_store<P::CPC>(m, red, tid, G, PL, C, part + ((size_t)b * nblk + blk) * C * 5);
+}
+
+// ---------------------------------------------------------------------------------
 // Partial sums layout: part[((b*nblk + blk)*C + c)*5 + s], s = {sum x, sum y, sum x^2, sum y^2, sum xy}.
 template <typename P>
 __global__ __launch_bounds__(256) void stats_nhwc_kernel(const typename P::T *__restrict__ feat, int B, int HW, int C,
@@ -74,43 +215,28 @@ __global__ __launch_bounds__(256) void stats_nhwc_kernel(const typename P::T *__
   const int g = tid % G, pl = tid / G;
   const int p_begin = blk * pix_per_block;
   const int p_end = min(HW, p_begin + pix_per_block);
-  double acc[P::CPC][5];
-#pragma unroll
-  for (int e = 0; e < P::CPC; ++e)
-#pragma unroll
-    for (int s = 0; s < 5; ++s) acc[e][s] = 0.0;
   const T *fx = feat + (size_t)b * HW * C + g * P::CPC;
   const T *fy = feat + (size_t)(B + b) * HW * C + g * P::CPC;
-  if (pl < PL) {
-#pragma unroll 2
-    for (int p = p_begin + pl; p < p_end; p += PL) {
-      const tvec vx = *reinterpret_cast<const tvec *>(fx + (size_t)p * C);
-      const tvec vy = *reinterpret_cast<const tvec *>(fy + (size_t)p * C);
+  ShiftedMoments<P::CPC> m;
+  m.init();
+  if (p_begin + pl < p_end) {
+    const tvec vx = *reinterpret_cast<const tvec *>(fx + (size_t)(p_begin + pl) * C);
+    const tvec vy = *reinterpret_cast<const tvec *>(fy + (size_t)(p_begin + pl) * C);
 #pragma unroll
-      for (int e = 0; e < P::CPC; ++e) {
-        const double x = (double)P::to_f(vx[e]), y = (double)P::to_f(vy[e]);
-        acc[e][0] += x;
-        acc[e][1] += y;
-        acc[e][2] = fma(x, x, acc[e][2]);
-        acc[e][3] = fma(y, y, acc[e][3]);
-        acc[e][4] = fma(x, y, acc[e][4]);
-      }
+    for (int e = 0; e < P::CPC; ++e) {
+      m.px[e] = P::to_f(vx[e]);
+      m.py[e] = P::to_f(vy[e]);
     }
   }
-  double *dst = part + ((size_t)b * nblk + blk) * C * 5;
+#pragma unroll 4
+  for (int p = p_begin + pl; p < p_end; p += PL) {
+    const tvec vx = *reinterpret_cast<const tvec *>(fx + (size_t)p * C);
+    const tvec vy = *reinterpret_cast<const tvec *>(fy + (size_t)p * C);
+    m.n += 1;
 #pragma unroll
-  for (int s = 0; s < 5; ++s) {
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < P::CPC; ++e) red[tid * P::CPC + e] = acc[e][s];
-    __syncthreads();
-    for (int c = tid; c < C; c += 256) {
-      const int cg = c / P::CPC, ce = c % P::CPC;
-      double sum = 0.0;
-      for (int q = 0; q < PL; ++q) sum += red[(q * G + cg) * P::CPC + ce];
-      dst[(size_t)c * 5 + s] = sum;
-    }
+    for (int e = 0; e < P::CPC; ++e) m.add(e, P::to_f(vx[e]), P::to_f(vy[e]));
   }
+  reduce_store<P::CPC>(m, red, tid, G, PL, C, part + ((size_t)b * nblk + blk) * C * 5);
 }
 
 // float32 NCHW planes: grid (B*C, nblk).  fx, fy: (B, C, HW).
@@ -150,20 +276,27 @@ __global__ __launch_bounds__(256) void stats_nchw_kernel(const float *__restrict
 }
 
 // ---------------------------------------------------------------------------------
+// One wave per (pair, channel): lanes stride over the per-block partial sums, then a shuffle
+// tree; the mean / variance / covariance -> S1, S2 arithmetic is done in fp64.
 __global__ __launch_bounds__(256) void finalize_kernel(const double *__restrict__ part, StageDesc d,
                                                        float *__restrict__ s1, float *__restrict__ s2) {
   const int b = blockIdx.y;
-  const int gc = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int gc = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (gc >= d.ctot) return;
   int k = 0;
   while (k + 1 < d.nstage && gc >= d.coff[k + 1]) ++k;
   const int c = gc - d.coff[k];
   const double *p = part + d.part_off[k] + ((size_t)b * d.nblk[k] * d.c[k] + c) * 5;
   double s[5] = {0, 0, 0, 0, 0};
-  for (int blk = 0; blk < d.nblk[k]; ++blk) {
+  for (int blk = lane; blk < d.nblk[k]; blk += 64) {
 #pragma unroll
     for (int q = 0; q < 5; ++q) s[q] += p[(size_t)blk * d.c[k] * 5 + q];
   }
+#pragma unroll
+  for (int q = 0; q < 5; ++q)
+    for (int off = 32; off > 0; off >>= 1) s[q] += __shfl_down(s[q], off, 64);
+  if (lane) return;
   const double inv = 1.0 / (double)d.hw[k];
   const double mx = s[0] * inv, my = s[1] * inv;
   const double vx = s[2] * inv - mx * mx, vy = s[3] * inv - my * my;
@@ -241,17 +374,27 @@ int l2pool(const void *in, int n, int H, int W, int C, int prec, void *out, hipS
   return NQA_E_ARG;
 }
 
-// pixels per block for the NHWC statistics kernel: 64 pixels per thread column.
-int stats_nhwc_ppb(int C, int prec) {
+// Work split of the NHWC statistics kernels: `units` loop items (pixels, or output pixels for
+// the fused pool+stats pass) per image pair; each block takes a contiguous strip.  Threads
+// take 4..16 items each (every block also writes C*5 doubles of partial sums, so very short
+// strips would cost more in partials than they read), sized for ~1024 blocks over the batch,
+// and never more than ~4096 so the finalize pass stays short.
+int stats_units_per_block(int units, int C, int prec, int B) {
   const int cpc = prec == NQA_PREC_F32 ? 4 : 8;
   const int PL = 256 / (C / cpc);
-  return 64 * PL;
+  if (B < 1) B = 1;
+  long per_thread = (long)units * B / ((long)PL * 1024);
+  per_thread = per_thread < 4 ? 4 : (per_thread > 16 ? 16 : per_thread);
+  int upb = (int)per_thread * PL;
+  const int max_blocks = 4096 / B > 16 ? 4096 / B : 16;
+  if (cdiv(units, upb) > max_blocks) upb = cdiv(cdiv(units, max_blocks), PL) * PL;
+  return upb;
 }
 int stats_nchw_ppb(int HW) { return HW > 65536 ? 65536 : (HW > 0 ? HW : 1); }
 
 template <typename P>
 static int launch_stats_nhwc(const void *feat, int B, int HW, int C, double *part, hipStream_t st) {
-  const int ppb = stats_nhwc_ppb(C, P::ID);
+  const int ppb = stats_units_per_block(HW, C, P::ID, B);
   dim3 grid(cdiv(HW, ppb), B);
   TimedLaunch t(NQA_K_STATS, st);
   stats_nhwc_kernel<P><<<grid, 256, 0, st>>>(reinterpret_cast<const typename P::T *>(feat), B, HW, C, ppb, part);
@@ -268,6 +411,29 @@ int stats_nhwc(const void *feat, int B, int HW, int C, int prec, double *part, h
   return NQA_E_ARG;
 }
 
+template <typename P>
+static int launch_pool_stats(const void *feat, int B, int H, int W, int C, void *pooled, double *part,
+                             hipStream_t st) {
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const int upb = stats_units_per_block(Ho * Wo, C, P::ID, B);
+  dim3 grid(cdiv(Ho * Wo, upb), B);
+  TimedLaunch t(NQA_K_POOL, st);
+  pool_stats_kernel<P><<<grid, 256, 0, st>>>(reinterpret_cast<const typename P::T *>(feat),
+                                             reinterpret_cast<typename P::T *>(pooled), B, H, W, C, Ho, Wo, upb, part);
+  return check_launch("pool_stats");
+}
+
+// tap (2B images: x then y) -> pooled (2B images) + statistics partials of the B pairs
+int pool_stats(const void *feat, int B, int H, int W, int C, int prec, void *pooled, double *part, hipStream_t st) {
+  switch (prec) {
+    case NQA_PREC_F32: return launch_pool_stats<PrecF32>(feat, B, H, W, C, pooled, part, st);
+    case NQA_PREC_BF16: return launch_pool_stats<PrecBF16>(feat, B, H, W, C, pooled, part, st);
+    case NQA_PREC_F16: return launch_pool_stats<PrecF16>(feat, B, H, W, C, pooled, part, st);
+  }
+  set_error("pool_stats: unknown prec %d", prec);
+  return NQA_E_ARG;
+}
+
 int stats_nchw(const float *fx, const float *fy, int B, int C, int HW, double *part, hipStream_t st) {
   const int ppb = stats_nchw_ppb(HW);
   dim3 grid(B * C, cdiv(HW, ppb));
@@ -277,7 +443,7 @@ int stats_nchw(const float *fx, const float *fy, int B, int C, int HW, double *p
 }
 
 int finalize(const double *part, const StageDesc &d, int B, float *s1, float *s2, hipStream_t st) {
-  dim3 grid(cdiv(d.ctot, 256), B);
+  dim3 grid(cdiv(d.ctot, 4), B);
   TimedLaunch t(NQA_K_STATS, st);
   finalize_kernel<<<grid, 256, 0, st>>>(part, d, s1, s2);
   return check_launch("finalize");
