@@ -1,0 +1,89 @@
+"""Frame sharding + the single score all-gather, on CPU with the gloo backend (world_size 2).
+
+The GPU kernels are not involved: a stub scorer stands in for the model so that the
+partitioning, padding and gather logic of nerf_qa_amd.sharding (what bench.py --gpus N and
+video.score_video use under RCCL) is exercised where no GPU exists.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_frames, batch, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nerf_qa_amd import sharding
+    calls = []
+
+    def score_batch(lo, hi):
+        calls.append((lo, hi))
+        return torch.arange(lo, hi, dtype=torch.float32) * 0.5 + 1.0
+
+    full = sharding.score_frames_sharded(score_batch, n_frames, batch, torch.device("cpu"))
+    q.put((rank, full.numpy(), calls))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_frames,batch", [(10, 4), (7, 3), (1, 8), (33, 32)])
+def test_sharded_scores_gathered_on_every_rank(n_frames, batch):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_frames, batch, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = np.arange(n_frames, dtype=np.float32) * 0.5 + 1.0
+    seen = []
+    for rank, full, calls in results:
+        assert np.array_equal(full, want), f"rank {rank} got {full}"
+        seen += calls
+    # every frame scored exactly once, in batches no longer than `batch`
+    covered = sorted(i for lo, hi in seen for i in range(lo, hi))
+    assert covered == list(range(n_frames))
+    assert all(0 < hi - lo <= batch for lo, hi in seen)
+
+
+def test_shard_range_partition():
+    from nerf_qa_amd.sharding import shard_range
+    for n in (0, 1, 7, 8, 9, 10000):
+        for world in (1, 2, 3, 4, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            for (a, b), (c, d) in zip(spans, spans[1:]):
+                assert b == c and a <= b and c <= d
+            assert max(b - a for a, b in spans) <= -(-n // world) if n else True
+
+
+def test_gather_without_process_group():
+    from nerf_qa_amd.sharding import gather_scores
+    t = torch.arange(5, dtype=torch.float32)
+    assert torch.equal(gather_scores(t, 5), t)
+
+
+def test_video_columns():
+    from nerf_qa_amd.video import format_frame_scores, video_columns
+    s = np.array([0.1, 0.2, 0.4], dtype=np.float32)
+    c = video_columns("DISTS", s)
+    assert abs(c["DISTS"] - float(np.mean(s.astype(np.float64)))) < 1e-12
+    assert abs(c["DISTS_std"] - float(np.std(s.astype(np.float64)))) < 1e-12
+    assert c["DISTS_min"] == pytest.approx(0.1) and c["DISTS_max"] == pytest.approx(0.4)
+    assert format_frame_scores(s[:2]) == "[1.000000e-01, 2.000000e-01]"
