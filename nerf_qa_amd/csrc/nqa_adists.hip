@@ -679,8 +679,11 @@ int nqa_adists_forward(const float *x, const float *y, int B, int H, int W, cons
 
   // ---- pyramids (x images [0,B), y images [B,2B)) with the global statistics per tap ----
   if ((rc = stats_nchw(x, y, B, 3, H * W, part + p.sd.part_off[0], st))) return rc;
-  if ((rc = conv1_1(x, B, H, W, packed, prec, base + p.bufA, st))) return rc;
-  if ((rc = conv1_1(y, B, H, W, packed, prec, base + p.bufA + (size_t)B * H * W * 64 * esz, st))) return rc;
+  const bool fused1 = prec != NQA_PREC_F32;
+  if (!fused1) {
+    if ((rc = conv1_1(x, B, H, W, packed, prec, base + p.bufA, st))) return rc;
+    if ((rc = conv1_1(y, B, H, W, packed, prec, base + p.bufA + (size_t)B * H * W * 64 * esz, st))) return rc;
+  }
   {
     // same chaining as nqa_vgg_pyramid, taps kept
     void *bufA = base + p.bufA, *bufB = base + p.bufB, *cur = bufA;
@@ -688,7 +691,11 @@ int nqa_adists_forward(const float *x, const float *y, int B, int H, int W, cons
       const ConvSpec &cs = kConvs[layer];
       const int k = cs.stage;
       void *dst = cs.last ? taps[k] : (cur == bufA ? bufB : bufA);
-      if ((rc = conv3x3(cur, 2 * B, p.h[k + 1], p.w[k + 1], layer, packed, prec, dst, st))) return rc;
+      if (layer == 1 && fused1) {
+        if ((rc = conv1_fused(x, y, B, 2 * B, H, W, packed, prec, dst, st))) return rc;
+      } else if ((rc = conv3x3(cur, 2 * B, p.h[k + 1], p.w[k + 1], layer, packed, prec, dst, st))) {
+        return rc;
+      }
       cur = dst;
       if (cs.last) {
         double *pk = part + p.sd.part_off[k + 1];

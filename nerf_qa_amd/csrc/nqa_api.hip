@@ -56,7 +56,7 @@ TimedLaunch::~TimedLaunch() {
 // ---- packed weight blob -------------------------------------------------------------
 static size_t layer_bytes(int layer, int prec) {
   const ConvSpec &c = kConvs[layer];
-  if (layer == 0) return align_up(27 * 64 * 4 + 64 * 4, 256);
+  if (layer == 0) return align_up(27 * 64 * 4 + 64 * 4, 256) + 6144;
   return align_up((size_t)c.cin * c.cout * 9 * prec_elem_bytes(prec), 256) + align_up((size_t)c.cout * 4, 256);
 }
 size_t layer_offset(int layer, int prec) {
@@ -64,6 +64,7 @@ size_t layer_offset(int layer, int prec) {
   for (int l = 0; l < layer; ++l) o += layer_bytes(l, prec);
   return o;
 }
+size_t layer0_mfma_offset(int prec) { return layer_offset(0, prec) + align_up(27 * 64 * 4 + 64 * 4, 256); }
 size_t layer_bias_offset(int layer, int prec) {
   const ConvSpec &c = kConvs[layer];
   if (layer == 0) return layer_offset(0, prec) + 27 * 64 * 4;
@@ -121,22 +122,34 @@ static size_t act_bytes(int n, int H, int W, int prec) {
   return align_up((size_t)n * H * W * 64 * prec_elem_bytes(prec), 256);
 }
 
-// Runs layers 1..12 and the four L2-pools on `n` images whose conv1_1 output sits in bufA.
-// Stage k's last conv writes into taps[k] when taps is given, else into the ping-pong pair.
+// Runs the 13 convs and the four L2-pools on `n` images: images [0,nx) come from x, the rest from
+// y (fp32 NCHW).  Stage 1 is the fused conv1_1+conv1_2 kernel in the 16-bit modes and two kernels
+// in f32.  Stage k's last conv writes into taps[k] when taps is given, else into the ping-pong pair.
 // on_tap(k, tap, Hk, Wk, Ck, pool_dst) is called once that conv is enqueued; pool_dst is where
 // the stage's L2-pool output must go (null after stage 5).  It returns 1 if it pooled the tap
 // itself (the fused pool+statistics pass), 0 to have the plain L2-pool run, <0 on error.
 template <typename F>
-static int run_stages(void *bufA, void *bufB, int n, int H, int W, const void *packed, int prec, void *const *taps,
-                      F on_tap, hipStream_t st) {
+static int run_stages(const float *x, const float *y, int nx, void *bufA, void *bufB, int n, int H, int W,
+                      const void *packed, int prec, void *const *taps, F on_tap, hipStream_t st) {
   const PyrDims d = pyr_dims(H, W);
   void *cur = bufA;
   int rc;
+  const bool fused1 = prec != NQA_PREC_F32;
+  if (!fused1) {
+    if ((rc = conv1_1(x, nx, H, W, packed, prec, bufA, st))) return rc;
+    if (n > nx && (rc = conv1_1(y, n - nx, H, W, packed, prec,
+                                static_cast<char *>(bufA) + (size_t)nx * H * W * 64 * prec_elem_bytes(prec), st)))
+      return rc;
+  }
   for (int layer = 1; layer < NQA_NUM_CONVS; ++layer) {
     const ConvSpec &cs = kConvs[layer];
     const int k = cs.stage;
     void *dst = (cs.last && taps) ? taps[k] : (cur == bufA ? bufB : bufA);
-    if ((rc = conv3x3(cur, n, d.h[k], d.w[k], layer, packed, prec, dst, st))) return rc;
+    if (layer == 1 && fused1) {
+      if ((rc = conv1_fused(x, y, nx, n, H, W, packed, prec, dst, st))) return rc;
+    } else if ((rc = conv3x3(cur, n, d.h[k], d.w[k], layer, packed, prec, dst, st))) {
+      return rc;
+    }
     cur = dst;
     if (cs.last) {
       void *pdst = k < 4 ? ((cur == bufA) ? bufB : bufA) : nullptr;
@@ -258,6 +271,17 @@ int nqa_pack_vgg_weights(const float *const w_host[NQA_NUM_CONVS], const float *
       for (int c = 0; c < 3; ++c)
         for (int t = 0; t < 9; ++t) w0[(t * 3 + c) * 64 + co] = w_host[0][(co * 3 + c) * 9 + t];
     memcpy(blob + layer_bias_offset(0, prec), b_host[0], 64 * 4);
+    if (prec != NQA_PREC_F32) {  // MFMA A fragments for the fused stage-1 kernel
+      uint16_t *wm = reinterpret_cast<uint16_t *>(blob + layer0_mfma_offset(prec));
+      for (int ky = 0; ky < 3; ++ky)
+        for (int co = 0; co < 64; ++co)
+          for (int hh = 0; hh < 2; ++hh)
+            for (int j = 0; j < 8; ++j) {
+              const int kx = 2 * hh + j / 4, c = j % 4;
+              const float v = (kx < 3 && c < 3) ? w_host[0][(co * 3 + c) * 9 + ky * 3 + kx] : 0.f;
+              wm[((ky * 64 + co) * 2 + hh) * 8 + j] = prec == NQA_PREC_BF16 ? f32_to_bf16(v) : f32_to_f16(v);
+            }
+    }
   }
   const int cpc = prec == NQA_PREC_F32 ? 4 : 8, kc = 4 * cpc;
   for (int l = 1; l < NQA_NUM_CONVS; ++l) {
@@ -370,9 +394,8 @@ int nqa_vgg_pyramid(const float *x, int n, int H, int W, const void *packed, int
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
   char *bufA = static_cast<char *>(ws), *bufB = bufA + ab;
-  int rc;
-  if ((rc = conv1_1(x, n, H, W, packed, prec, bufA, st))) return rc;
-  return run_stages(bufA, bufB, n, H, W, packed, prec, taps, [](int, void *, int, int, int, void *) { return 0; }, st);
+  return run_stages(x, nullptr, n, bufA, bufB, n, H, W, packed, prec, taps,
+                    [](int, void *, int, int, int, void *) { return 0; }, st);
 }
 
 int nqa_dists_forward(const float *x, const float *y, int B, int H, int W, const void *packed, int prec, void *ws,
@@ -397,10 +420,8 @@ int nqa_dists_forward(const float *x, const float *y, int B, int H, int W, const
   // feature 0 is the raw image (DISTS_pt.py:103): statistics straight from the inputs
   if ((rc = stats_nchw(x, y, B, 3, H * W, part + p.d.part_off[0], st))) return rc;
   // x images occupy [0,B), y images [B,2B) of one NHWC batch
-  if ((rc = conv1_1(x, B, H, W, packed, prec, bufA, st))) return rc;
-  if ((rc = conv1_1(y, B, H, W, packed, prec, bufA + (size_t)B * H * W * 64 * prec_elem_bytes(prec), st))) return rc;
   rc = run_stages(
-      bufA, bufB, n, H, W, packed, prec, nullptr,
+      x, y, B, bufA, bufB, n, H, W, packed, prec, nullptr,
       [&](int k, void *tap, int hk, int wk, int ck, void *pool_dst) {
         double *pk = part + p.d.part_off[k + 1];
         if (!pool_dst) return stats_nhwc(tap, B, hk * wk, ck, prec, pk, st);

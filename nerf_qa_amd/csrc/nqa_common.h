@@ -95,6 +95,9 @@ static const int kChnOff[NQA_NUM_TAPS] = {0, 3, 67, 195, 451, 963};
 static constexpr size_t kZeroPage = 256;
 size_t layer_offset(int layer, int prec);
 size_t layer_bias_offset(int layer, int prec);
+// conv1_1 again as 16-bit MFMA A fragments [ky][cout][h][8], k = ky*16 + kx*4 + c (zero for
+// kx = 3 or c = 3), 6144 bytes, for the fused stage-1 kernel (zeros in the f32 blob)
+size_t layer0_mfma_offset(int prec);
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -113,6 +116,8 @@ struct StageDesc {
 // ---- host launchers shared between translation units ---------------------------------
 void set_conv_variant(int v);
 int conv1_1(const float *x, int n, int H, int W, const void *packed, int prec, void *out, hipStream_t st);
+int conv1_fused(const float *x, const float *y, int B, int n, int H, int W, const void *packed, int prec, void *out,
+                hipStream_t st);
 int conv3x3(const void *in, int n, int H, int W, int layer, const void *packed, int prec, void *out, hipStream_t st);
 int l2pool(const void *in, int n, int H, int W, int C, int prec, void *out, hipStream_t st);
 int stats_units_per_block(int units, int C, int prec, int B);

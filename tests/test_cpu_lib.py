@@ -60,9 +60,22 @@ def test_pack_roundtrip(prec, np_convs, lib):
     esz = 4 if prec == "f32" else 2
     al = lambda v: (v + 255) // 256 * 256
     assert not blob[:256].any()  # zero page: the source of out-of-image halo pixels
-    off = 256 + al(27 * 64 * 4 + 64 * 4)
+    off = 256 + al(27 * 64 * 4 + 64 * 4) + 6144  # + conv1_1 as 16-bit MFMA fragments (fused stage-1 kernel)
     w0 = blob[256:256 + 27 * 64 * 4].view(np.float32).reshape(9, 3, 64)
     assert np.array_equal(w0, np_convs[0][0].reshape(64, 3, 9).transpose(2, 1, 0))
+    wm = blob[256 + al(27 * 64 * 4 + 64 * 4):][:6144].view(np.uint16).reshape(3, 64, 2, 8)
+    if prec == "f32":
+        assert not wm.any()
+    else:
+        conv = (lambda a: a.astype(np.float16).view(np.uint16)) if prec == "f16" else \
+            (lambda a: torch.from_numpy(a.copy()).to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16))
+        w00 = np_convs[0][0]  # (64, 3, 3, 3) = [cout][c][ky][kx]
+        for ky in range(3):
+            for hh in range(2):
+                for j in range(8):
+                    kx, c = 2 * hh + j // 4, j % 4
+                    want = conv(w00[:, c, ky, kx]) if (kx < 3 and c < 3) else np.zeros(64, np.uint16)
+                    assert np.array_equal(wm[ky, :, hh, j], want)
     for l in (1, 2, 7, 12):
         cin, cout = ops.CONV_CIN[l], ops.CONV_COUT[l]
         o = off + sum(al(ops.CONV_CIN[i] * ops.CONV_COUT[i] * 9 * esz) + al(ops.CONV_COUT[i] * 4) for i in range(1, l))
