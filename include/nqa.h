@@ -74,6 +74,12 @@ int nqa_pack_vgg_weights(const float *const w_host[NQA_NUM_CONVS], const float *
 int nqa_conv1_1(const float *x_nchw, int n, int H, int W, const void *packed_w, int prec, void *out_nhwc,
                 void *stream);
 
+/* Stage 1 in one kernel (16-bit modes only): conv1_1 as above followed by conv1_2+ReLU
+ * (features[0..3], DISTS_pt.py:36-37), the 64-channel intermediate staying in LDS.
+ * x: dev float32 NCHW (n,3,H,W); out: dev NHWC (n,H,W,64) = relu1_2. */
+int nqa_conv1_fused(const float *x_nchw, int n, int H, int W, const void *packed_w, int prec, void *out_nhwc,
+                    void *stream);
+
 /* conv3x3 stride 1 pad 1 + bias + ReLU for VGG layer `layer` (1..12), NHWC in/out
  * (torchvision Conv2d+ReLU pairs, DISTS_pt.py:36-49). */
 int nqa_conv3x3_relu(const void *in_nhwc, int n, int H, int W, int layer, const void *packed_w, int prec,

@@ -26,6 +26,7 @@ _SIGNATURES = {
     "nqa_packed_weights_bytes": (_sz, [_i]),
     "nqa_pack_vgg_weights": (_i, [C.POINTER(_vp), C.POINTER(_vp), _i, _vp]),
     "nqa_conv1_1": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp]),
+    "nqa_conv1_fused": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp]),
     "nqa_conv3x3_relu": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     "nqa_l2pool": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "nqa_nhwc_to_nchw_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),

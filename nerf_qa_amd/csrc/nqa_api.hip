@@ -318,6 +318,15 @@ int nqa_conv1_1(const float *x, int n, int H, int W, const void *packed, int pre
   return conv1_1(x, n, H, W, packed, prec, out, static_cast<hipStream_t>(stream));
 }
 
+int nqa_conv1_fused(const float *x, int n, int H, int W, const void *packed, int prec, void *out, void *stream) {
+  if (!x || !packed || !out) {
+    set_error("conv1_fused: null pointer");
+    return NQA_E_ARG;
+  }
+  if (bad_dims("conv1_fused", n, H, W, prec)) return NQA_E_ARG;
+  return conv1_fused(x, nullptr, n, n, H, W, packed, prec, out, static_cast<hipStream_t>(stream));
+}
+
 int nqa_conv3x3_relu(const void *in, int n, int H, int W, int layer, const void *packed, int prec, void *out,
                      void *stream) {
   if (!in || !packed || !out) {

@@ -327,19 +327,35 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void conv3x3_igemm_kernel(
 // conv1_1 + conv1_2 fused (16-bit modes): the whole of stage 1 without the 64-channel
 // full-resolution intermediate ever touching HBM.
 // ---------------------------------------------------------------------------------
-// Persistent blocks (one per CU) keep ALL of conv1_2's weights in LDS (9 taps x 64 x 64 x 2 B =
-// 72 KB) and walk over 8x32-pixel output tiles.  Per tile:
-//   raw    the (x-mean)/std image patch (12x36x3, zero outside the image = conv1_1's padding)
-//          goes to LDS as 16-bit [row][col][4];
-//   phase1 conv1_1 on MFMA for the 10x34 halo patch: with the contraction index ordered
-//          k = ky*16 + kx*4 + c (kx, c padded to 4 with zero weights) a lane's 8-element
-//          B fragment is 16 contiguous bytes of the raw patch, so K = 48 = three MFMAs per
-//          32x32 tile; bias+ReLU, zero outside the image (conv1_2's padding), written straight
-//          into the swizzled [chunk][pixel][64 B] image the implicit-GEMM loop reads;
-//   phase2 conv1_2: the 6-stage loop of conv3x3_igemm_kernel with nothing left to stream --
-//          no DMA, no barrier; next tile's raw pixels are fetched into registers meanwhile.
+// Persistent 8-wave blocks (one per CU) keep ALL of conv1_2's weights in LDS (9 taps x 64 x 64 x
+// 2 B = 72 KB) and walk over 4x32-pixel output tiles.  A tile goes through two phases:
+//   P1  conv1_1 for its 6x34 halo patch.  Per 32-pixel column tile a wave fetches the 4x36x3 raw
+//       pixels it needs (one work item ahead, into registers), writes them normalised
+//       ((x-mean)/std, zero outside the image = conv1_1's padding) as 16-bit [row][col][4] into
+//       its private LDS scratch and runs conv1_1 on MFMA: with the contraction index ordered
+//       k = ky*16 + kx*4 + c (kx, c padded to 4 with zero weights) a lane's 8-element B fragment
+//       is 16 contiguous bytes of that scratch, so K = 48 is three MFMAs per 32x32 tile.
+//       bias+ReLU, zero outside the image (conv1_2's padding), stored straight into the swizzled
+//       [chunk][pixel][64 B] image that P2 reads;
+//   P2  conv1_2: the 6-stage loop of conv3x3_igemm_kernel with nothing left to stream (no DMA, no
+//       barrier inside), bias+ReLU, NHWC store.
+// The block's two wave groups (waves 0-3, 4-7) each own a tile stream and run half a period
+// apart: while one group is in P2 (MFMA-bound) the other is in P1 (VALU/LDS-bound), so the two
+// waves of every SIMD complement each other.  One block barrier per half period.
+struct Conv1Fused {
+  typedef ConvGeom<1, 4, 2, 1, 32> G;  // per group: 64 ch x 128 px over 4 waves
+  static constexpr int A_TILE = 2 * G::A_BYTES;  // both 32-channel chunks of one tile
+  static constexpr int W2_BYTES = 2 * 9 * 64 * 64;
+  static constexpr int RAW_W = 40, RAW_WAVE_BYTES = 4 * RAW_W * 8;
+  static constexpr int W1_BYTES = 3 * 64 * 2 * 16;  // conv1_1 as MFMA A fragments [ky][cout][h][8]
+  static constexpr int A_OFF = 0, W2_OFF = 2 * A_TILE, RAW_OFF = W2_OFF + W2_BYTES;
+  static constexpr int W1_OFF = RAW_OFF + 8 * RAW_WAVE_BYTES, BIAS_OFF = W1_OFF + W1_BYTES;
+  static constexpr int LDS_BYTES = BIAS_OFF + 2 * 64 * 4;
+  static constexpr int NPT = (G::NQ + 31) / 32;  // 32-pixel column tiles of the halo patch (7)
+};
+
 template <typename P>
-__global__ __launch_bounds__(256) void conv1_fused_kernel(const float *__restrict__ x, const float *__restrict__ y,
+__global__ __launch_bounds__(512) void conv1_fused_kernel(const float *__restrict__ x, const float *__restrict__ y,
                                                           int B, const char *__restrict__ w1m,
                                                           const float *__restrict__ bias1,
                                                           const char *__restrict__ w2pk,
@@ -348,213 +364,241 @@ __global__ __launch_bounds__(256) void conv1_fused_kernel(const float *__restric
                                                           int tiles_y, int total_tiles) {
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef typename P::T T;
-  typedef ConvGeom<1, 4, 2, 2, 32> G;  // 64 ch x 256 px, 4 waves: same tile as the stand-alone layer
-  constexpr int RAW_W = 40, RAW_H = 12, RAW_BYTES = RAW_H * RAW_W * 8;
-  constexpr int W2_BYTES = 2 * 9 * 64 * 64;
-  constexpr int A_OFF = 0, W2_OFF = 2 * G::A_BYTES, RAW_OFF = W2_OFF + W2_BYTES;
+  typedef Conv1Fused F;
+  typedef F::G G;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
   const int HW = H * W;
-  const float mean[3] = {0.485f, 0.456f, 0.406f};
-  const float sd[3] = {0.229f, 0.224f, 0.225f};
+  const int grp = wave >> 2, w4 = wave & 3;
+  char *abuf = smem + F::A_OFF + grp * F::A_TILE;
+  char *raw = smem + F::RAW_OFF + wave * F::RAW_WAVE_BYTES;
 
-  // ---- one-time: zero the raw patch (4th channel / pad columns stay 0) and fetch conv1_2's weights ----
-  for (int i = tid; i < RAW_BYTES / 16; i += 256) {
+  // ---- one-time: zero the raw scratch (4th channel / pad columns stay 0), fetch the weights ----
+  for (int i = tid; i < 8 * F::RAW_WAVE_BYTES / 16; i += 512) {
     const u32x4 z = {0u, 0u, 0u, 0u};
-    reinterpret_cast<u32x4 *>(smem + RAW_OFF)[i] = z;
+    reinterpret_cast<u32x4 *>(smem + F::RAW_OFF)[i] = z;
   }
   {
     const __amdgpu_buffer_rsrc_t w_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(w2pk), 0, W2_BYTES, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(w2pk), 0, F::W2_BYTES, 0x00020000);
 #pragma unroll
-    for (int r = 0; r < W2_BYTES / 16 / 256; ++r)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void_t *)(smem + W2_OFF + (r * 256 + wave * 64) * 16), 16,
-                                               (r * 256 + tid) * 16, 0, 0, 0);
+    for (int r = 0; r < F::W2_BYTES / 16 / 512; ++r)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void_t *)(smem + F::W2_OFF + (r * 512 + wave * 64) * 16),
+                                               16, (r * 512 + tid) * 16, 0, 0, 0);
   }
-  // conv1_1 weights as MFMA A fragments: [ky][cout][h][8] -> registers
-  u32x4 w1f[2][3];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
-      w1f[i][ky] = *reinterpret_cast<const u32x4 *>(w1m + ((ky * 64 + i * 32 + l31) * 2 + h) * 16);
+  if (tid < F::W1_BYTES / 16)
+    reinterpret_cast<u32x4 *>(smem + F::W1_OFF)[tid] = reinterpret_cast<const u32x4 *>(w1m)[tid];
+  if (tid < 128) reinterpret_cast<float *>(smem + F::BIAS_OFF)[tid] = tid < 64 ? bias1[tid] : bias2[tid - 64];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-  // both bias vectors in registers: this lane's 4 consecutive channels of each (tile i, group g)
-  f32x4 b1r[2][4], b2r[2][4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      b1r[i][g] = *reinterpret_cast<const f32x4 *>(bias1 + i * 32 + 8 * g + 4 * h);
-      b2r[i][g] = *reinterpret_cast<const f32x4 *>(bias2 + i * 32 + 8 * g + 4 * h);
-    }
-  // per-lane constants of the conv1_2 loop (identical to conv3x3_igemm_kernel, wn = 0, wm = wave)
-  int w_base[2], w_sw[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int r64 = i * 32 + l31;
-    w_base[i] = W2_OFF + r64 * 64;
-    w_sw[i] = (r64 >> 2) & 3;
-  }
-  int q0[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int m = (wave * 2 + j) * 32 + l31;
-    q0[j] = (m >> 5) * G::HW_ + (m & 31);
-  }
-
-  // raw-patch plan: item i -> (row, col, c) of the 12x36x3 patch
-  int raw_lds[6], raw_c[6], raw_row[6], raw_col[6];
-#pragma unroll
-  for (int r = 0; r < 6; ++r) {
-    const int i = r * 256 + tid;
-    const int row = i / 108, rem = i - row * 108, col = rem / 3, c = rem - col * 3;
-    raw_row[r] = i < 1296 ? row : -100000;
-    raw_col[r] = col;
-    raw_c[r] = c;
-    raw_lds[r] = RAW_OFF + (row * RAW_W + col) * 8 + c * 2;
-  }
-  float rawv[6];  // raw (un-normalised) pixels of the next tile; NaN-free: 0 where outside the image
-  unsigned rawok = 0;
-  auto fetch_raw = [&](int tile) {
-    const int n = tile / (tiles_x * tiles_y), t2 = tile - n * (tiles_x * tiles_y);
-    const int by = t2 / tiles_x, bx = t2 - by * tiles_x;
-    const float *img = (n < B ? x + (size_t)n * 3 * HW : y + (size_t)(n - B) * 3 * HW);
-#pragma unroll
-    for (int r = 0; r < 6; ++r) {
-      const int gy = by * 8 - 2 + raw_row[r], gx = bx * 32 - 2 + raw_col[r];
-      const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-      float v = 0.f;
-      if (ok) v = img[(size_t)raw_c[r] * HW + gy * W + gx];  // normalised at write time: no wait here
-      rawv[r] = v;
-      rawok = ok ? (rawok | (1u << r)) : (rawok & ~(1u << r));
-    }
+  auto tile_coords = [&](int tile, int &n, int &x0, int &y0) {
+    n = tile / (tiles_x * tiles_y);
+    const int t2 = tile - n * (tiles_x * tiles_y), by = t2 / tiles_x;
+    x0 = (t2 - by * tiles_x) * 32;
+    y0 = by * 4;
   };
 
-  int tile = blockIdx.x;
-  if (tile < total_tiles) fetch_raw(tile);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // conv1_2 weights have landed (first barrier publishes them)
-
-  for (; tile < total_tiles; tile += gridDim.x) {
-    const int n = tile / (tiles_x * tiles_y), t2 = tile - n * (tiles_x * tiles_y);
-    const int by = t2 / tiles_x, bx = t2 - by * tiles_x;
-    const int x0 = bx * 32, y0 = by * 8;
-    __syncthreads();  // previous tile fully consumed (A image, raw patch)
+  // ---- P1 pieces: a wave owns column tiles pt = w4 and w4+4 (< 7) of its group's halo patch ----
+  const float mean[3] = {0.485f, 0.456f, 0.406f};
+  const float sd[3] = {0.229f, 0.224f, 0.225f};
+  int r_plan[7];  // item -> (row << 16 | col << 2 | c) of a 4x36x3 raw sub-patch, -1 = none
 #pragma unroll
-    for (int r = 0; r < 6; ++r)
-      if (raw_row[r] >= 0)
-        *reinterpret_cast<T *>(smem + raw_lds[r]) =
-            P::from_f((rawok >> r) & 1u ? (rawv[r] - mean[raw_c[r]]) / sd[raw_c[r]] : 0.f);
-    __syncthreads();
-
-    // ---- phase 1: conv1_1 for the 10x34 halo patch, 32 pixels per MFMA column tile ----
-    for (int pt = wave; pt < (G::NQ + 31) / 32; pt += 4) {
-      const int q = pt * 32 + l31;
-      const int qc = q < G::NQ ? q : G::NQ - 1;
-      const int hy = qc / G::HW_, hx = qc - hy * G::HW_;
-      f32x16 a1[2];
+  for (int r = 0; r < 7; ++r) {
+    const int i = r * 64 + lane;
+    const int row = i / 108, rem = i - row * 108, col = rem / 3;
+    r_plan[r] = i < 432 ? (row << 16 | col << 2 | (rem - col * 3)) : -1;
+  }
+  auto fetch = [&](int tile, int pt, float(&rv)[7], unsigned &okmask) {
+    int n, x0, y0;
+    tile_coords(tile, n, x0, y0);
+    const float *img = (n < B ? x + (size_t)n * 3 * HW : y + (size_t)(n - B) * 3 * HW);
+    const int r0 = (pt * 32) / G::HW_;  // first halo row this column tile touches
+    okmask = 0;
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) a1[i][r] = 0.f;
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-        const char *rp = smem + RAW_OFF + ((hy + ky) * RAW_W + hx + 2 * h) * 8;
-        const u32x2 lo = *reinterpret_cast<const u32x2 *>(rp), hi = *reinterpret_cast<const u32x2 *>(rp + 8);
-        const u32x4 bfr = {lo[0], lo[1], hi[0], hi[1]};
-#pragma unroll
-        for (int i = 0; i < 2; ++i) a1[i] = P::mma(w1f[i][ky], bfr, a1[i]);
-      }
-      const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-      const bool inside = q < G::NQ && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-      if (q < G::NQ) {
-        const int sw = (q >> 2) & 3;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const f32x4 b4 = b1r[i][g];
-            typedef __attribute__((ext_vector_type(4))) T t4;
-            t4 v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = P::from_f(inside ? fmaxf(a1[i][4 * g + e] + b4[e], 0.f) : 0.f);
-            *reinterpret_cast<t4 *>(smem + A_OFF + i * G::A_BYTES + q * 64 + ((g ^ sw) << 4) + h * 8) = v;
-          }
-        }
-      }
+    for (int r = 0; r < 7; ++r) {
+      const int row = r_plan[r] >> 16, col = (r_plan[r] >> 2) & 0x3FFF, c = r_plan[r] & 3;
+      const int gy = y0 - 2 + r0 + row, gx = x0 - 2 + col;
+      const bool ok = r_plan[r] >= 0 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      rv[r] = 0.f;
+#ifndef NQA_F_NO_FETCH
+      if (ok) rv[r] = img[(size_t)c * HW + gy * W + gx];
+#endif
+      okmask |= ok ? (1u << r) : 0u;
     }
-    __syncthreads();
-
-    // ---- phase 2: conv1_2 from LDS; the next tile's raw pixels are fetched underneath ----
-    if (tile + (int)gridDim.x < total_tiles) fetch_raw(tile + gridDim.x);
-    f32x16 acc[2][2];
+  };
+  auto finish = [&](int tile, int pt, const float(&rv)[7], unsigned okmask) {
+#ifdef NQA_F_NO_P1
+    asm volatile("" ::"v"(rv[0]), "v"(rv[1]), "v"(rv[2]), "v"(rv[3]), "v"(rv[4]), "v"(rv[5]), "v"(rv[6]), "v"(okmask));
+    return;
+#endif
+    int n, x0, y0;
+    tile_coords(tile, n, x0, y0);
+    const int r0 = (pt * 32) / G::HW_;
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+      const int row = r_plan[r] >> 16, col = (r_plan[r] >> 2) & 0x3FFF, c = r_plan[r] & 3;
+      const float mu = c == 0 ? mean[0] : c == 1 ? mean[1] : mean[2], sg = c == 0 ? sd[0] : c == 1 ? sd[1] : sd[2];
+      const float v = (okmask >> r) & 1u ? (rv[r] - mu) / sg : 0.f;
+      if (r_plan[r] >= 0) *reinterpret_cast<T *>(raw + (row * F::RAW_W + col) * 8 + c * 2) = P::from_f(v);
+    }
+    // the scratch is private to this wave: its own LDS writes are ordered before its reads
+    const int q = pt * 32 + l31;
+    const int qc = q < G::NQ ? q : G::NQ - 1;
+    const int hy = qc / G::HW_, hx = qc - hy * G::HW_;
+    f32x16 a1[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int r = 0; r < 16; ++r) a1[i][r] = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    auto load_frags = [&](int t, u32x4(&af)[2], u32x4(&bf)[2]) {  // t = 0..35: (cc, ky, kx, ks)
+    for (int ky = 0; ky < 3; ++ky) {
+      const char *rp = raw + ((hy - r0 + ky) * F::RAW_W + hx + 2 * h) * 8;
+      const u32x2 lo = *reinterpret_cast<const u32x2 *>(rp), hi = *reinterpret_cast<const u32x2 *>(rp + 8);
+      const u32x4 bfr = {lo[0], lo[1], hi[0], hi[1]};
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const u32x4 wf = *reinterpret_cast<const u32x4 *>(smem + F::W1_OFF + ((ky * 64 + i * 32 + l31) * 2 + h) * 16);
+        a1[i] = P::mma(wf, bfr, a1[i]);
+      }
+    }
+    const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+    const bool inside = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+    if (q < G::NQ) {
+      const int sw = (q >> 2) & 3;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 b4 = *reinterpret_cast<const f32x4 *>(smem + F::BIAS_OFF + (i * 32 + 8 * g + 4 * h) * 4);
+          typedef __attribute__((ext_vector_type(4))) T t4;
+          t4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = P::from_f(inside ? fmaxf(a1[i][4 * g + e] + b4[e], 0.f) : 0.f);
+          *reinterpret_cast<t4 *>(abuf + i * G::A_BYTES + q * 64 + ((g ^ sw) << 4) + h * 8) = v;
+        }
+      }
+    }
+  };
+  float rawA[7], rawB[7];
+  unsigned okA = 0, okB = 0;
+  const bool hasB = w4 + 4 < F::NPT;
+  // raw pixels of both of this wave's column tiles of `tile` -> registers (no wait)
+  auto fetch_both = [&](int tile) {
+    fetch(tile, w4, rawA, okA);
+    if (hasB) fetch(tile, w4 + 4, rawB, okB);
+  };
+  // precondition: fetch_both(tile) was issued (a phase earlier, so the loads have landed)
+  auto phase1 = [&](int tile) {
+    finish(tile, w4, rawA, okA);
+    if (hasB) finish(tile, w4 + 4, rawB, okB);
+  };
+
+  // ---- P2: conv1_2 of the group's tile; wave w4 owns tile row w4 ----
+  int w_base[2], w_sw[2];
+  const int q0 = w4 * G::HW_ + l31;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r64 = i * 32 + l31;
+    w_base[i] = F::W2_OFF + r64 * 64;
+    w_sw[i] = (r64 >> 2) & 3;
+  }
+  // `prefetch_tile` (< 0: none): the tile whose P1 this wave runs next; its first raw fetch is
+  // issued here so that it lands under the MFMAs
+  auto phase2 = [&](int tile, int prefetch_tile) {
+    int n, x0, y0;
+    tile_coords(tile, n, x0, y0);
+    if (prefetch_tile >= 0) fetch_both(prefetch_tile);
+    // make the per-lane bases opaque per tile: otherwise hipcc hoists all 108 fragment addresses
+    // of the unrolled loop out of the persistent tile loop and runs out of registers
+    int wb[2] = {w_base[0], w_base[1]}, qq = q0;
+    asm volatile("" : "+v"(wb[0]), "+v"(wb[1]), "+v"(qq));
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    auto load_frags = [&](int t, u32x4(&af)[2], u32x4 &bf) {  // t = 0..35: (cc, ky, kx, ks)
       const int st = t / 6, tt = t - st * 6, cc = st / 3, ky = st - cc * 3;
       const int kx = tt >> 1, ch = 2 * (tt & 1) + h;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
-        af[i] = *reinterpret_cast<const u32x4 *>(smem + w_base[i] + st * 12288 + kx * 4096 + ((ch ^ w_sw[i]) << 4));
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int q = q0[j] + ky * G::HW_ + kx;
-        bf[j] = *reinterpret_cast<const u32x4 *>(smem + A_OFF + cc * G::A_BYTES + q * 64 + ((ch ^ ((q >> 2) & 3)) << 4));
-      }
+        af[i] = *reinterpret_cast<const u32x4 *>(smem + wb[i] + st * 12288 + kx * 4096 + ((ch ^ w_sw[i]) << 4));
+      const int q = qq + ky * G::HW_ + kx;
+      bf = *reinterpret_cast<const u32x4 *>(abuf + cc * G::A_BYTES + q * 64 + ((ch ^ ((q >> 2) & 3)) << 4));
     };
-    auto mma_all = [&](const u32x4(&af)[2], const u32x4(&bf)[2]) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = P::mma(af[i], bf[j], acc[i][j]);
-    };
-    // one wave per SIMD here, so LDS latency is hidden by depth instead: fragments are read two
-    // k-steps ahead of their MFMAs (three register sets)
-    u32x4 af0[2], bf0[2], af1[2], bf1[2], af2[2], bf2[2];
+    // only two MFMAs per k-step here, so fragments are read TWO steps ahead (three register sets)
+    u32x4 af0[2], af1[2], af2[2], bf0, bf1, bf2;
     load_frags(0, af0, bf0);
+#ifdef NQA_F_NO_P2LOOP
+    acc[0] = P::mma(af0[0], bf0, acc[0]);
+    acc[1] = P::mma(af0[1], bf0, acc[1]);
+#else
     load_frags(1, af1, bf1);
 #pragma unroll
     for (int t = 0; t < 36; t += 3) {
       load_frags(t + 2, af2, bf2);
       __builtin_amdgcn_sched_barrier(0);
-      mma_all(af0, bf0);
+      acc[0] = P::mma(af0[0], bf0, acc[0]);
+      acc[1] = P::mma(af0[1], bf0, acc[1]);
       __builtin_amdgcn_sched_barrier(0);
       if (t + 3 < 36) load_frags(t + 3, af0, bf0);
       __builtin_amdgcn_sched_barrier(0);
-      mma_all(af1, bf1);
+      acc[0] = P::mma(af1[0], bf1, acc[0]);
+      acc[1] = P::mma(af1[1], bf1, acc[1]);
       __builtin_amdgcn_sched_barrier(0);
       if (t + 4 < 36) load_frags(t + 4, af1, bf1);
       __builtin_amdgcn_sched_barrier(0);
-      mma_all(af2, bf2);
+      acc[0] = P::mma(af2[0], bf2, acc[0]);
+      acc[1] = P::mma(af2[1], bf2, acc[1]);
       __builtin_amdgcn_sched_barrier(0);
     }
-    // ---- epilogue: bias + ReLU -> NHWC ----
+#endif
+    const int gy = y0 + w4, gx = x0 + l31;
+#ifdef NQA_F_NO_STORE
+    if (gy < -5) {
+#else
+    if (gy < H && gx < W) {
+#endif
+      T *o = out + ((size_t)(n * H + gy) * W + gx) * 64 + 4 * h;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int m = (wave * 2 + j) * 32 + l31;
-      const int gy = y0 + (m >> 5), gx = x0 + (m & 31);
-      if (gy < H && gx < W) {
-        T *o = out + ((size_t)(n * H + gy) * W + gx) * 64 + 4 * h;
+      for (int i = 0; i < 2; ++i) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 b4 = *reinterpret_cast<const f32x4 *>(smem + F::BIAS_OFF + (64 + i * 32 + 8 * g + 4 * h) * 4);
+          typedef __attribute__((ext_vector_type(4))) T t4;
+          t4 s4;
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int co = i * 32 + 8 * g;
-            const f32x4 b4 = b2r[i][g];
-            typedef __attribute__((ext_vector_type(4))) T t4;
-            t4 s4;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) s4[e] = P::from_f(fmaxf(acc[i][j][4 * g + e] + b4[e], 0.f));
-            *reinterpret_cast<t4 *>(o + co) = s4;
-          }
+          for (int e = 0; e < 4; ++e) s4[e] = P::from_f(fmaxf(acc[i][4 * g + e] + b4[e], 0.f));
+          *reinterpret_cast<t4 *>(o + i * 32 + 8 * g) = s4;
         }
       }
     }
+  };
+
+  // ---- schedule: group g's k-th tile is (2*blockIdx.x + g) + k * 2*gridDim.x ----
+  const int stride = 2 * gridDim.x;
+  const int first = 2 * blockIdx.x + grp;
+  const int K = first < total_tiles ? (total_tiles - 1 - first) / stride + 1 : 0;       // my tiles
+  const int K0 = 2 * (int)blockIdx.x < total_tiles ? (total_tiles - 1 - 2 * (int)blockIdx.x) / stride + 1 : 0;  // group 0's
+  if (K > 0) fetch_both(first);
+  __syncthreads();  // weights, biases and the zeroed scratch are visible
+  if (grp == 0 && K > 0) phase1(first);
+  __syncthreads();
+  for (int k = 0; k < K0; ++k) {  // K0 >= group 1's count, so both groups see the same barriers
+    const int t_k = first + k * stride, t_n = t_k + stride;
+    if (grp == 0) {
+      if (k < K) phase2(t_k, k + 1 < K ? t_n : -1);
+    } else {
+      if (k < K) phase1(t_k);
+    }
+    __syncthreads();
+    if (grp == 0) {
+      if (k + 1 < K) phase1(t_n);
+    } else {
+      if (k < K) phase2(t_k, k + 1 < K ? t_n : -1);
+    }
+    __syncthreads();
   }
 #endif
 }
@@ -626,8 +670,7 @@ static int g_num_cus = 0;
 template <typename P>
 static int launch_conv1_fused(const float *x, const float *y, int B, int n, int H, int W, const char *packed,
                               void *out, hipStream_t st) {
-  typedef ConvGeom<1, 4, 2, 2, 32> G;
-  constexpr int LDS = 2 * G::A_BYTES + 2 * 9 * 64 * 64 + 12 * 40 * 8;
+  constexpr int LDS = Conv1Fused::LDS_BYTES;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv1_fused_kernel<P>),
@@ -646,14 +689,14 @@ static int launch_conv1_fused(const float *x, const float *y, int B, int n, int 
     }
     g_num_cus = prop.multiProcessorCount;
   }
-  const int tiles_x = cdiv(W, 32), tiles_y = cdiv(H, 8), total = n * tiles_x * tiles_y;
-  const int grid = total < g_num_cus ? total : g_num_cus;  // one persistent block per CU
+  const int tiles_x = cdiv(W, 32), tiles_y = cdiv(H, 4), total = n * tiles_x * tiles_y;
+  const int grid = cdiv(total, 2) < g_num_cus ? cdiv(total, 2) : g_num_cus;  // one persistent block per CU
   const char *w1m = packed + layer0_mfma_offset(P::ID);
   const float *b1 = reinterpret_cast<const float *>(packed + layer_bias_offset(0, P::ID));
   const char *w2 = packed + layer_offset(1, P::ID);
   const float *b2 = reinterpret_cast<const float *>(packed + layer_bias_offset(1, P::ID));
   TimedLaunch t(NQA_K_CONV, st);
-  conv1_fused_kernel<P><<<grid, 256, LDS, st>>>(x, y, B, w1m, b1, w2, b2, reinterpret_cast<typename P::T *>(out), H, W,
+  conv1_fused_kernel<P><<<grid, 512, LDS, st>>>(x, y, B, w1m, b1, w2, b2, reinterpret_cast<typename P::T *>(out), H, W,
                                                 tiles_x, tiles_y, total);
   return check_launch("conv1_fused");
 }

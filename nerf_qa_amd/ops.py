@@ -78,6 +78,18 @@ def conv1_1(x: torch.Tensor, packed: torch.Tensor, prec) -> torch.Tensor:
     return out
 
 
+def conv1_fused(x: torch.Tensor, packed: torch.Tensor, prec) -> torch.Tensor:
+    """relu1_2 (NHWC) straight from the image: conv1_1 + conv1_2 in one kernel (16-bit modes)."""
+    p = prec_id(prec)
+    dev = _need_cuda(x, packed)
+    x = _f32c(x)
+    n, c, h, w = x.shape
+    assert c == 3
+    out = torch.empty((n, h, w, 64), dtype=PREC_DTYPE[p], device=dev)
+    check(lib().nqa_conv1_fused(ptr(x), n, h, w, ptr(packed), p, ptr(out), stream_ptr(dev)))
+    return out
+
+
 def conv3x3_relu(inp: torch.Tensor, layer: int, packed: torch.Tensor, prec) -> torch.Tensor:
     p = prec_id(prec)
     dev = _need_cuda(inp, packed)
