@@ -287,6 +287,109 @@ __global__ __launch_bounds__(256) void adists_window_kernel(const typename P::T 
   }
 }
 
+// ---------------------------------------------------------------------------------
+// The windowed pass for the NHWC taps (stages 1..5), lanes = channels.
+//
+// A wave owns one output column x of image pair b and a strip of up to 64 output rows, and walks
+// down the input rows with one channel per lane (so every load is a coalesced 64-channel row of
+// one pixel and nothing goes through LDS).  Per input row it takes the 21-tap HORIZONTAL sums of
+// the five products from 21+21 neighbour loads, pushes them into a 21-row ring held in registers
+// (105 VGPRs), and once the ring is full takes the 21-tap VERTICAL sums -- the ring is never
+// rotated: slot s of phase j gets weight g[(s-j-1) mod 21], read as 21 consecutive scalars of a
+// doubled table.  That is the separable minimum of 2 x 21 x 5 FMAs per (pixel, channel).
+// T, S and the gamma term follow per lane; a 64-lane butterfly sums them over channels and the
+// total is banked in the accumulator of lane (row - strip start), so the strip's three output
+// columns leave as plain stores after the last channel block: no atomics, deterministic.
+struct Gauss2 {
+  float g[42];  // g[t] = gaussian[t mod 21]
+};
+
+template <typename P>
+__global__ __launch_bounds__(256) void adists_window_lanes_kernel(
+    const typename P::T *__restrict__ fx, const typename P::T *__restrict__ fy, int H, int W, int C,
+    const float *__restrict__ q, int B, int ctot, int coff, const float *__restrict__ wgt, Gauss gw,
+    const float *__restrict__ g2, float *__restrict__ gamma, float *__restrict__ tw, float *__restrict__ sw) {
+  typedef typename P::T T;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.z;
+  const int Ho = H - (kWin - 1), Wo = W - (kWin - 1);
+  const int ox = blockIdx.x * 4 + wave;  // 4 adjacent columns per block: their neighbour loads overlap in L1
+  if (ox >= Wo) return;
+  const int oy0 = blockIdx.y * 64;
+  const int nout = min(64, Ho - oy0);
+  const size_t st = (size_t)B * ctot, qo = (size_t)b * ctot + coff;
+  float acc_g = 0.f, acc_t = 0.f, acc_s = 0.f;  // lane l: output row oy0 + l
+  for (int cb = 0; cb < C; cb += 64) {
+    const int c = cb + lane;
+    const float ix = q[0 * st + qo + c], iy = q[1 * st + qo + c], wc = wgt[qo + c];
+    const T *px = fx + ((size_t)(b * H + oy0) * W + ox) * C + c;
+    const T *py = fy + ((size_t)(b * H + oy0) * W + ox) * C + c;
+    float r0[kWin], r1[kWin], r2[kWin], r3[kWin], r4[kWin];  // ring: hx, hy, hxx, hyy, hxy per slot
+#pragma unroll
+    for (int s = 0; s < kWin; ++s) r0[s] = r1[s] = r2[s] = r3[s] = r4[s] = 0.f;
+    int slot = 0;
+    for (int rr = 0; rr < nout + kWin - 1; ++rr) {
+      float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f, h4 = 0.f;
+#pragma unroll
+      for (int j = 0; j < kWin; ++j) {
+        const float xv = P::to_f(px[(size_t)j * C]), yv = P::to_f(py[(size_t)j * C]);
+        const float gx_ = gw.g[j] * xv, gy_ = gw.g[j] * yv;
+        h0 += gx_;
+        h1 += gy_;
+        h2 = fmaf(gx_, xv, h2);
+        h3 = fmaf(gy_, yv, h3);
+        h4 = fmaf(gx_, yv, h4);
+      }
+      px += (size_t)W * C;
+      py += (size_t)W * C;
+      switch (slot) {  // static register names: one case runs
+#define NQA_RING(S) case S: r0[S] = h0; r1[S] = h1; r2[S] = h2; r3[S] = h3; r4[S] = h4; break;
+        NQA_RING(0) NQA_RING(1) NQA_RING(2) NQA_RING(3) NQA_RING(4) NQA_RING(5) NQA_RING(6)
+        NQA_RING(7) NQA_RING(8) NQA_RING(9) NQA_RING(10) NQA_RING(11) NQA_RING(12) NQA_RING(13)
+        NQA_RING(14) NQA_RING(15) NQA_RING(16) NQA_RING(17) NQA_RING(18) NQA_RING(19) NQA_RING(20)
+#undef NQA_RING
+      }
+      if (rr >= kWin - 1) {
+        const float *gv = g2 + (kWin - 1 - slot);  // weight of ring slot s at this phase
+        float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f;
+#pragma unroll
+        for (int s = 0; s < kWin; ++s) {
+          const float g = gv[s];
+          m0 = fmaf(g, r0[s], m0);
+          m1 = fmaf(g, r1[s], m1);
+          m2 = fmaf(g, r2[s], m2);
+          m3 = fmaf(g, r3[s], m3);
+          m4 = fmaf(g, r4[s], m4);
+        }
+        float gterm = (m2 - m0 * m0) / (m0 + 1e-12f);
+        const float mx = ix * m0, my = iy * m1;
+        const float vx = ix * ix * m2 - mx * mx, vy = iy * iy * m3 - my * my;
+        const float cov = ix * iy * m4 - mx * my;
+        float tt = wc * ((2.f * mx * my + 1e-6f) / (mx * mx + my * my + 1e-6f));
+        float ss = wc * ((2.f * cov + 1e-6f) / (vx + vy + 1e-6f));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+          gterm += __shfl_xor(gterm, off, 64);
+          tt += __shfl_xor(tt, off, 64);
+          ss += __shfl_xor(ss, off, 64);
+        }
+        if (lane == rr - (kWin - 1)) {
+          acc_g += gterm;
+          acc_t += tt;
+          acc_s += ss;
+        }
+      }
+      slot = slot == kWin - 1 ? 0 : slot + 1;
+    }
+  }
+  if (lane < nout) {
+    const size_t o = ((size_t)b * Ho + oy0 + lane) * Wo + ox;
+    gamma[o] = acc_g / (float)C;
+    tw[o] = acc_t;
+    sw[o] = acc_s;
+  }
+}
+
 // Global branch of one stage (maps smaller than the window; ADISTS.py:91-97,176-180): one
 // block per image pair, from the per-channel global statistics.  Outputs 1x1 "maps".
 __global__ __launch_bounds__(256) void adists_global_kernel(const float *__restrict__ q, int B, int ctot, int coff,
@@ -516,7 +619,7 @@ static Gauss make_gauss() {
 
 struct APlan {
   // byte offsets into the workspace
-  size_t bufA, bufB, taps[5], img4x, img4y, part, q, ent, wgt, maps[NQA_NUM_TAPS][4], acc, total;
+  size_t bufA, bufB, taps[5], img4x, img4y, part, q, ent, wgt, maps[NQA_NUM_TAPS][4], acc, g2, total;
   StageDesc sd;
   EntDesc ed;
   int h[NQA_NUM_TAPS], w[NQA_NUM_TAPS], c[NQA_NUM_TAPS];  // feature dims per tap (k=0 raw image)
@@ -597,6 +700,7 @@ static APlan make_plan(int B, int H, int W, int prec) {
     for (int j = 0; j < 4; ++j) p.maps[k][j] = take((size_t)B * p.mh[k] * p.mw[k] * 4);
   }
   p.acc = take((size_t)6 * B * sizeof(ChainAcc));
+  p.g2 = take(42 * sizeof(float));
   p.total = off;
   return p;
 }
@@ -632,6 +736,19 @@ static int launch_window(const void *fx, const void *fy, int B, int H, int W, in
                                                   reinterpret_cast<const typename P::T *>(fy), H, W, C, creal, q, B,
                                                   ctot, coff, wgt, g, gamma, tw, sw);
   return check_launch("adists_window");
+}
+
+template <typename P>
+static int launch_window_lanes(const void *fx, const void *fy, int B, int H, int W, int C, const float *q, int ctot,
+                               int coff, const float *wgt, const Gauss &g, const float *g2, float *gamma, float *tw,
+                               float *sw, hipStream_t st) {
+  const int Ho = H - (kWin - 1), Wo = W - (kWin - 1);
+  dim3 grid(cdiv(Wo, 4), cdiv(Ho, 64), B);
+  TimedLaunch t(NQA_K_ADISTS, st);
+  adists_window_lanes_kernel<P><<<grid, 256, 0, st>>>(reinterpret_cast<const typename P::T *>(fx),
+                                                      reinterpret_cast<const typename P::T *>(fy), H, W, C, q, B, ctot,
+                                                      coff, wgt, g, g2, gamma, tw, sw);
+  return check_launch("adists_window_lanes");
 }
 
 }  // namespace nqa
@@ -748,6 +865,15 @@ int nqa_adists_forward(const float *x, const float *y, int B, int H, int W, cons
   }
   // ---- heavy pass: gamma / TW / SW maps per stage ----
   static const Gauss gauss = make_gauss();
+  float *g2 = reinterpret_cast<float *>(base + p.g2);
+  {
+    static Gauss2 g2h;
+    for (int t = 0; t < 42; ++t) g2h.g[t] = gauss.g[t % kWin];
+    if (hipMemcpyAsync(g2, g2h.g, sizeof(g2h.g), hipMemcpyHostToDevice, st) != hipSuccess) {
+      set_error("adists_forward: cannot upload the window table");
+      return NQA_E_LAUNCH;
+    }
+  }
   for (int k = 0; k < 6; ++k) {
     float *gamma = reinterpret_cast<float *>(base + p.maps[k][0]);
     float *tw = reinterpret_cast<float *>(base + p.maps[k][1]);
@@ -764,9 +890,9 @@ int nqa_adists_forward(const float *x, const float *y, int B, int H, int W, cons
       const char *tx = static_cast<const char *>(taps[k - 1]);
       const char *ty = tx + (size_t)B * p.h[k] * p.w[k] * p.c[k] * esz;
       switch (prec) {
-        case NQA_PREC_F32: rc = launch_window<PrecF32>(tx, ty, B, p.h[k], p.w[k], p.c[k], p.c[k], q, ctot, p.sd.coff[k], wgt, gauss, gamma, tw, sw, st); break;
-        case NQA_PREC_BF16: rc = launch_window<PrecBF16>(tx, ty, B, p.h[k], p.w[k], p.c[k], p.c[k], q, ctot, p.sd.coff[k], wgt, gauss, gamma, tw, sw, st); break;
-        default: rc = launch_window<PrecF16>(tx, ty, B, p.h[k], p.w[k], p.c[k], p.c[k], q, ctot, p.sd.coff[k], wgt, gauss, gamma, tw, sw, st); break;
+        case NQA_PREC_F32: rc = launch_window_lanes<PrecF32>(tx, ty, B, p.h[k], p.w[k], p.c[k], q, ctot, p.sd.coff[k], wgt, gauss, g2, gamma, tw, sw, st); break;
+        case NQA_PREC_BF16: rc = launch_window_lanes<PrecBF16>(tx, ty, B, p.h[k], p.w[k], p.c[k], q, ctot, p.sd.coff[k], wgt, gauss, g2, gamma, tw, sw, st); break;
+        default: rc = launch_window_lanes<PrecF16>(tx, ty, B, p.h[k], p.w[k], p.c[k], q, ctot, p.sd.coff[k], wgt, gauss, g2, gamma, tw, sw, st); break;
       }
     }
     if (rc) return rc;

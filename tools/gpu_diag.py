@@ -4,7 +4,7 @@ import time
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __file__.rsplit("/", 2)[0])
 from nerf_qa_amd import ops, synth  # noqa: E402
 
 FLOP_PER_PIXEL = 2 * 9 * sum(ci * co / (4 ** s) for (ci, co, s) in

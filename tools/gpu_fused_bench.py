@@ -1,7 +1,7 @@
 """Time the fused stage-1 kernel alone (development aid; NQA_LIB selects an ablation build)."""
 import sys
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __file__.rsplit("/", 2)[0])
 from nerf_qa_amd import ops, synth  # noqa: E402
 dev = torch.device("cuda:0")
 packed = ops.pack_vgg_weights(synth.vgg16_weights(1234), "f16").to(dev)

@@ -7,7 +7,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __file__.rsplit("/", 2)[0])
 from nerf_qa_amd import ops, synth  # noqa: E402
 
 dev = torch.device("cuda:0")
