@@ -305,7 +305,7 @@ struct Gauss2 {
 };
 
 template <typename P>
-__global__ __launch_bounds__(256) void adists_window_lanes_kernel(
+__global__ __launch_bounds__(256, 2) void adists_window_lanes_kernel(
     const typename P::T *__restrict__ fx, const typename P::T *__restrict__ fy, int H, int W, int C,
     const float *__restrict__ q, int B, int ctot, int coff, const float *__restrict__ wgt, Gauss gw,
     const float *__restrict__ g2, float *__restrict__ gamma, float *__restrict__ tw, float *__restrict__ sw) {
@@ -317,6 +317,7 @@ __global__ __launch_bounds__(256) void adists_window_lanes_kernel(
   if (ox >= Wo) return;
   const int oy0 = blockIdx.y * 64;
   const int nout = min(64, Ho - oy0);
+  const int nrows = nout + kWin - 1;
   const size_t st = (size_t)B * ctot, qo = (size_t)b * ctot + coff;
   float acc_g = 0.f, acc_t = 0.f, acc_s = 0.f;  // lane l: output row oy0 + l
   for (int cb = 0; cb < C; cb += 64) {
@@ -324,62 +325,77 @@ __global__ __launch_bounds__(256) void adists_window_lanes_kernel(
     const float ix = q[0 * st + qo + c], iy = q[1 * st + qo + c], wc = wgt[qo + c];
     const T *px = fx + ((size_t)(b * H + oy0) * W + ox) * C + c;
     const T *py = fy + ((size_t)(b * H + oy0) * W + ox) * C + c;
-    float r0[kWin], r1[kWin], r2[kWin], r3[kWin], r4[kWin];  // ring: hx, hy, hxx, hyy, hxy per slot
+    // ring of the last 21 rows' horizontal sums, slot = grp*7 + sub.  The row loop is unrolled by 7
+    // so `sub` is a compile-time index; `grp` (0..2) is dynamic and resolved by wave-uniform selects
+    // (a switch over 21 slots makes hipcc shuttle the whole ring through AGPRs every row).
+    float r0[3][7], r1[3][7], r2[3][7], r3[3][7], r4[3][7];
 #pragma unroll
-    for (int s = 0; s < kWin; ++s) r0[s] = r1[s] = r2[s] = r3[s] = r4[s] = 0.f;
-    int slot = 0;
-    for (int rr = 0; rr < nout + kWin - 1; ++rr) {
-      float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f, h4 = 0.f;
+    for (int g = 0; g < 3; ++g)
 #pragma unroll
-      for (int j = 0; j < kWin; ++j) {
-        const float xv = P::to_f(px[(size_t)j * C]), yv = P::to_f(py[(size_t)j * C]);
-        const float gx_ = gw.g[j] * xv, gy_ = gw.g[j] * yv;
-        h0 += gx_;
-        h1 += gy_;
-        h2 = fmaf(gx_, xv, h2);
-        h3 = fmaf(gy_, yv, h3);
-        h4 = fmaf(gx_, yv, h4);
-      }
-      px += (size_t)W * C;
-      py += (size_t)W * C;
-      switch (slot) {  // static register names: one case runs
-#define NQA_RING(S) case S: r0[S] = h0; r1[S] = h1; r2[S] = h2; r3[S] = h3; r4[S] = h4; break;
-        NQA_RING(0) NQA_RING(1) NQA_RING(2) NQA_RING(3) NQA_RING(4) NQA_RING(5) NQA_RING(6)
-        NQA_RING(7) NQA_RING(8) NQA_RING(9) NQA_RING(10) NQA_RING(11) NQA_RING(12) NQA_RING(13)
-        NQA_RING(14) NQA_RING(15) NQA_RING(16) NQA_RING(17) NQA_RING(18) NQA_RING(19) NQA_RING(20)
-#undef NQA_RING
-      }
-      if (rr >= kWin - 1) {
-        const float *gv = g2 + (kWin - 1 - slot);  // weight of ring slot s at this phase
-        float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f;
+      for (int u = 0; u < 7; ++u) r0[g][u] = r1[g][u] = r2[g][u] = r3[g][u] = r4[g][u] = 0.f;
+    int grp = 0;
+    for (int rr0 = 0; rr0 < nrows; rr0 += 7) {
 #pragma unroll
-        for (int s = 0; s < kWin; ++s) {
-          const float g = gv[s];
-          m0 = fmaf(g, r0[s], m0);
-          m1 = fmaf(g, r1[s], m1);
-          m2 = fmaf(g, r2[s], m2);
-          m3 = fmaf(g, r3[s], m3);
-          m4 = fmaf(g, r4[s], m4);
+      for (int sub = 0; sub < 7; ++sub) {
+        const int rr = rr0 + sub;
+        if (rr < nrows) {
+          float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f, h4 = 0.f;
+#pragma unroll
+          for (int j = 0; j < kWin; ++j) {
+            const float xv = P::to_f(px[(size_t)j * C]), yv = P::to_f(py[(size_t)j * C]);
+            const float gx_ = gw.g[j] * xv, gy_ = gw.g[j] * yv;
+            h0 += gx_;
+            h1 += gy_;
+            h2 = fmaf(gx_, xv, h2);
+            h3 = fmaf(gy_, yv, h3);
+            h4 = fmaf(gx_, yv, h4);
+          }
+          px += (size_t)W * C;
+          py += (size_t)W * C;
+#pragma unroll
+          for (int g = 0; g < 3; ++g) {
+            const bool hit = grp == g;
+            r0[g][sub] = hit ? h0 : r0[g][sub];
+            r1[g][sub] = hit ? h1 : r1[g][sub];
+            r2[g][sub] = hit ? h2 : r2[g][sub];
+            r3[g][sub] = hit ? h3 : r3[g][sub];
+            r4[g][sub] = hit ? h4 : r4[g][sub];
+          }
+          if (rr >= kWin - 1) {
+            const float *gv = g2 + (kWin - 1 - (grp * 7 + sub));  // weight of ring slot s at this phase
+            float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f;
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+              for (int u = 0; u < 7; ++u) {
+                const float wv = gv[g * 7 + u];
+                m0 = fmaf(wv, r0[g][u], m0);
+                m1 = fmaf(wv, r1[g][u], m1);
+                m2 = fmaf(wv, r2[g][u], m2);
+                m3 = fmaf(wv, r3[g][u], m3);
+                m4 = fmaf(wv, r4[g][u], m4);
+              }
+            float gterm = (m2 - m0 * m0) / (m0 + 1e-12f);
+            const float mx = ix * m0, my = iy * m1;
+            const float vx = ix * ix * m2 - mx * mx, vy = iy * iy * m3 - my * my;
+            const float cov = ix * iy * m4 - mx * my;
+            float tt = wc * ((2.f * mx * my + 1e-6f) / (mx * mx + my * my + 1e-6f));
+            float ss = wc * ((2.f * cov + 1e-6f) / (vx + vy + 1e-6f));
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+              gterm += __shfl_xor(gterm, off, 64);
+              tt += __shfl_xor(tt, off, 64);
+              ss += __shfl_xor(ss, off, 64);
+            }
+            if (lane == rr - (kWin - 1)) {
+              acc_g += gterm;
+              acc_t += tt;
+              acc_s += ss;
+            }
+          }
         }
-        float gterm = (m2 - m0 * m0) / (m0 + 1e-12f);
-        const float mx = ix * m0, my = iy * m1;
-        const float vx = ix * ix * m2 - mx * mx, vy = iy * iy * m3 - my * my;
-        const float cov = ix * iy * m4 - mx * my;
-        float tt = wc * ((2.f * mx * my + 1e-6f) / (mx * mx + my * my + 1e-6f));
-        float ss = wc * ((2.f * cov + 1e-6f) / (vx + vy + 1e-6f));
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-          gterm += __shfl_xor(gterm, off, 64);
-          tt += __shfl_xor(tt, off, 64);
-          ss += __shfl_xor(ss, off, 64);
-        }
-        if (lane == rr - (kWin - 1)) {
-          acc_g += gterm;
-          acc_t += tt;
-          acc_s += ss;
-        }
       }
-      slot = slot == kWin - 1 ? 0 : slot + 1;
+      grp = grp == 2 ? 0 : grp + 1;
     }
   }
   if (lane < nout) {
