@@ -125,7 +125,23 @@ struct EntDesc {
   int ctot;
 };
 
-__global__ __launch_bounds__(256) void adists_weights_kernel(const double *__restrict__ part, EntDesc d,
+// fold the per-block entropy partials: one wave per (image, channel) -> hsum[b][ctot]
+__global__ __launch_bounds__(256) void adists_entropy_fold_kernel(const double *__restrict__ part, EntDesc d,
+                                                                  float *__restrict__ hsum) {
+  const int b = blockIdx.y, lane = threadIdx.x & 63;
+  const int gc = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (gc >= d.ctot) return;
+  int k = 0;
+  while (k + 1 < NQA_NUM_TAPS && gc >= d.coff[k + 1]) ++k;
+  const int c = gc - d.coff[k];
+  const double *p = part + d.part_off[k] + (size_t)b * d.nblk[k] * d.c[k] + c;
+  double s = 0.0;
+  for (int blk = lane; blk < d.nblk[k]; blk += 64) s += p[(size_t)blk * d.c[k]];
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if (lane == 0) hsum[(size_t)b * d.ctot + gc] = (float)s;
+}
+
+__global__ __launch_bounds__(256) void adists_weights_kernel(const float *__restrict__ hsum, EntDesc d,
                                                              float *__restrict__ wgt /* [B][ctot] */) {
   __shared__ float h[NQA_TOTAL_CHNS];
   __shared__ double red[256];
@@ -144,11 +160,9 @@ __global__ __launch_bounds__(256) void adists_weights_kernel(const double *__res
   for (int k = 0; k < NQA_NUM_TAPS; ++k) {
     double loc = 0.0;
     for (int c = tid; c < d.creal[k]; c += 256) {
-      const double *p = part + d.part_off[k] + (size_t)b * d.nblk[k] * d.c[k] + c;
-      double s = 0.0;
-      for (int blk = 0; blk < d.nblk[k]; ++blk) s += p[(size_t)blk * d.c[k]];
-      h[d.coff[k] + c] = (float)s;
-      loc += (double)(float)s;
+      const float s = hsum[(size_t)b * d.ctot + d.coff[k] + c];
+      h[d.coff[k] + c] = s;
+      loc += (double)s;
     }
     const float tot = (float)block_sum(loc);
     for (int c = tid; c < d.creal[k]; c += 256)
@@ -679,10 +693,15 @@ static APlan make_plan(int B, int H, int W, int prec) {
   for (int k = 0; k < 6; ++k) {
     const int hw = p.h[k] * p.w[k];
     // taps 1..4 get their statistics inside the fused pool pass (items = pooled pixels)
-    const int units = (k >= 1 && k <= 4) ? ((p.h[k] + 1) / 2) * ((p.w[k] + 1) / 2) : hw;
-    const int ppb = k == 0 ? stats_nchw_ppb(hw) : stats_units_per_block(units, p.c[k], prec, B);
+    int nblk;
+    if (k == 0)
+      nblk = cdiv(hw, stats_nchw_ppb(hw));
+    else if (k <= 4)
+      nblk = pool_stats_tiles((p.h[k] + 1) / 2, (p.w[k] + 1) / 2, p.c[k], prec, B, nullptr, nullptr);
+    else
+      nblk = cdiv(hw, stats_units_per_block(hw, p.c[k], prec, B));
     p.sd.part_off[k] = doff;
-    p.sd.nblk[k] = cdiv(units, ppb);
+    p.sd.nblk[k] = nblk;
     p.sd.hw[k] = hw;
     p.sd.c[k] = p.c[k];
     p.sd.coff[k] = coff;
@@ -875,8 +894,11 @@ int nqa_adists_forward(const float *x, const float *y, int B, int H, int W, cons
     if (rc) return rc;
   }
   {
+    // hsum reuses the q[2] (sum_x) rows: they are dead once the entropy kernels have run
+    float *hsum = q + 2 * qst;
     TimedLaunch t(NQA_K_ADISTS, st);
-    adists_weights_kernel<<<B, 256, 0, st>>>(ent, p.ed, wgt);
+    adists_entropy_fold_kernel<<<dim3(cdiv(ctot, 4), B), 256, 0, st>>>(ent, p.ed, hsum);
+    adists_weights_kernel<<<B, 256, 0, st>>>(hsum, p.ed, wgt);
     if ((rc = check_launch("adists_weights"))) return rc;
   }
   // ---- heavy pass: gamma / TW / SW maps per stage ----

@@ -183,19 +183,24 @@ struct StatsPlan {
   StageDesc d;
   size_t doubles;
 };
-// `units[k]`: loop items of stage k's statistics pass -- pixels, or output pixels where the fused
-// pool+statistics kernel is used (null: every stage runs the NCHW plane kernel over HW[k]).
-static StatsPlan stats_plan(int B, const int *C, const int *HW, const int *units, int nstage, int prec) {
+// `pooled[k]` = {Ho, Wo} where stage k's statistics come out of the fused pool+statistics pass
+// ({0,0}: the plain NHWC pass over HW[k]); pooled == null: every stage runs the NCHW plane kernel.
+static StatsPlan stats_plan(int B, const int *C, const int *HW, const int (*pooled)[2], int nstage, int prec) {
   StatsPlan p;
   memset(&p, 0, sizeof(p));
   long off = 0;
   int coff = 0;
   for (int k = 0; k < nstage; ++k) {
-    const bool nchw = !units || k == 0;
-    const int n_units = nchw ? HW[k] : units[k];
-    const int ppb = nchw ? stats_nchw_ppb(HW[k]) : stats_units_per_block(n_units, C[k], prec, B);
+    const bool nchw = !pooled || k == 0;
+    int nblk;
+    if (nchw)
+      nblk = cdiv(HW[k], stats_nchw_ppb(HW[k]));
+    else if (pooled[k][0])
+      nblk = pool_stats_tiles(pooled[k][0], pooled[k][1], C[k], prec, B, nullptr, nullptr);
+    else
+      nblk = cdiv(HW[k], stats_units_per_block(HW[k], C[k], prec, B));
     p.d.part_off[k] = off;
-    p.d.nblk[k] = cdiv(n_units, ppb);
+    p.d.nblk[k] = nblk;
     p.d.hw[k] = HW[k];
     p.d.c[k] = C[k];
     p.d.coff[k] = coff;
@@ -367,15 +372,17 @@ int nqa_nhwc_to_nchw_f32(const void *in, int n, int H, int W, int C, int prec, f
 // inside the fused pool+statistics pass (items = pooled pixels), tap 5 by the plain NHWC pass.
 static StatsPlan dists_stats_plan(int B, int H, int W, int prec) {
   const PyrDims d = pyr_dims(H, W);
-  int C[6], HW[6], units[6];
+  int C[6], HW[6], pooled[6][2];
   C[0] = 3;
-  HW[0] = units[0] = H * W;
+  HW[0] = H * W;
+  pooled[0][0] = pooled[0][1] = 0;
   for (int k = 0; k < 5; ++k) {
     C[k + 1] = kChns[k + 1];
     HW[k + 1] = d.h[k] * d.w[k];
-    units[k + 1] = k < 4 ? d.h[k + 1] * d.w[k + 1] : HW[k + 1];
+    pooled[k + 1][0] = k < 4 ? d.h[k + 1] : 0;
+    pooled[k + 1][1] = k < 4 ? d.w[k + 1] : 0;
   }
-  return stats_plan(B, C, HW, units, 6, prec);
+  return stats_plan(B, C, HW, pooled, 6, prec);
 }
 
 size_t nqa_workspace_bytes(int n_images, int H, int W, int prec) {

@@ -122,6 +122,7 @@ int conv3x3(const void *in, int n, int H, int W, int layer, const void *packed, 
 int l2pool(const void *in, int n, int H, int W, int C, int prec, void *out, hipStream_t st);
 int stats_units_per_block(int units, int C, int prec, int B);
 int stats_nchw_ppb(int HW);
+int pool_stats_tiles(int Ho, int Wo, int C, int prec, int B, int *tr, int *tc);
 int pool_stats(const void *feat, int B, int H, int W, int C, int prec, void *pooled, double *part, hipStream_t st);
 int stats_nhwc(const void *feat, int B, int HW, int C, int prec, double *part, hipStream_t st);
 int stats_nchw(const float *fx, const float *fy, int B, int C, int HW, double *part, hipStream_t st);

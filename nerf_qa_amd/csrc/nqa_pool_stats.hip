@@ -125,7 +125,7 @@ __device__ inline void reduce_store(const ShiftedMoments<CPC> &m, double *red, i
 template <typename P>
 __global__ __launch_bounds__(256) void pool_stats_kernel(const typename P::T *__restrict__ feat,
                                                          typename P::T *__restrict__ pooled, int B, int H, int W,
-                                                         int C, int Ho, int Wo, int units_per_block,
+                                                         int C, int Ho, int Wo, int TR, int TC, int tiles_x,
                                                          double *__restrict__ part) {
   typedef typename P::T T;
   typedef __attribute__((ext_vector_type(P::CPC))) T tvec;
@@ -135,16 +135,18 @@ __global__ __launch_bounds__(256) void pool_stats_kernel(const typename P::T *__
   const int G = C / P::CPC, PL = 256 / G;
   const int g = tid % G, pl = tid / G;
   const int HoWo = Ho * Wo;
-  const int u_begin = blk * units_per_block;
-  const int u_end = min(HoWo, u_begin + units_per_block);
+  // the block's output pixels form a TR x TC tile (not a 1-D strip): the 3x3 windows of vertically
+  // adjacent outputs share an input row, and inside one block that re-read hits L1/L2 instead of HBM
+  const int by = blk / tiles_x, bx = blk - by * tiles_x;
+  const int oy0 = by * TR, ox0 = bx * TC, tile_units = TR * TC;
   const T *fx = feat + (size_t)b * H * W * C + g * P::CPC;
   const T *fy = feat + (size_t)(B + b) * H * W * C + g * P::CPC;
   T *ox_ = pooled + (size_t)b * HoWo * C + g * P::CPC;
   T *oy_ = pooled + (size_t)(B + b) * HoWo * C + g * P::CPC;
   ShiftedMoments<P::CPC> m;
   m.init();
-  if (u_begin + pl < u_end) {  // pivot = this thread's first owned sample (the window centre, always in range)
-    const int u = u_begin + pl, oy = u / Wo, ox = u - oy * Wo;
+  if (pl < tile_units) {  // pivot = a sample near this thread's first pixel (a window centre, always in range)
+    const int oy = min(oy0 + pl / TC, Ho - 1), ox = min(ox0 + pl % TC, Wo - 1);
     const size_t o = ((size_t)(2 * oy) * W + 2 * ox) * C;
     const tvec vx = *reinterpret_cast<const tvec *>(fx + o), vy = *reinterpret_cast<const tvec *>(fy + o);
 #pragma unroll
@@ -153,8 +155,10 @@ __global__ __launch_bounds__(256) void pool_stats_kernel(const typename P::T *__
       m.py[e] = P::to_f(vy[e]);
     }
   }
-  for (int u = u_begin + pl; u < u_end; u += PL) {
-    const int oy = u / Wo, ox = u - oy * Wo;
+  for (int t = pl; t < tile_units; t += PL) {
+    const int oy = oy0 + t / TC, ox = ox0 + t % TC;
+    if (oy >= Ho || ox >= Wo) continue;
+    const int u = oy * Wo + ox;
     // All 18 loads go out unconditionally from clamped coordinates, back to back (a branch per
     // tap would serialise them into 9 round trips); an out-of-image tap is then zeroed for the
     // pool (zero padding) and skipped by the sums.
@@ -411,15 +415,29 @@ int stats_nhwc(const void *feat, int B, int HW, int C, int prec, double *part, h
   return NQA_E_ARG;
 }
 
+// Tile shape of the fused pool+statistics pass for an Ho x Wo pooled map: up to 8 rows tall,
+// units_per_block pixels in all; returns the number of tiles (= blocks per image pair).
+int pool_stats_tiles(int Ho, int Wo, int C, int prec, int B, int *tr, int *tc) {
+  const int upb = stats_units_per_block(Ho * Wo, C, prec, B);
+  int TR = 8;
+  while (TR > 1 && (upb % TR || upb / TR < 4 || TR > Ho)) TR >>= 1;
+  const int TC = upb / TR;
+  if (tr) *tr = TR;
+  if (tc) *tc = TC;
+  return cdiv(Wo, TC) * cdiv(Ho, TR);
+}
+
 template <typename P>
 static int launch_pool_stats(const void *feat, int B, int H, int W, int C, void *pooled, double *part,
                              hipStream_t st) {
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
-  const int upb = stats_units_per_block(Ho * Wo, C, P::ID, B);
-  dim3 grid(cdiv(Ho * Wo, upb), B);
+  int TR, TC;
+  const int nblk = pool_stats_tiles(Ho, Wo, C, P::ID, B, &TR, &TC);
+  dim3 grid(nblk, B);
   TimedLaunch t(NQA_K_POOL, st);
   pool_stats_kernel<P><<<grid, 256, 0, st>>>(reinterpret_cast<const typename P::T *>(feat),
-                                             reinterpret_cast<typename P::T *>(pooled), B, H, W, C, Ho, Wo, upb, part);
+                                             reinterpret_cast<typename P::T *>(pooled), B, H, W, C, Ho, Wo, TR, TC,
+                                             cdiv(Wo, TC), part);
   return check_launch("pool_stats");
 }
 
