@@ -647,14 +647,15 @@ static int launch_conv(const void *in, int n, int H, int W, int layer, const cha
   const char *wpk = packed + layer_offset(layer, P::ID);
   const float *bias = reinterpret_cast<const float *>(packed + layer_bias_offset(layer, P::ID));
   const bool narrow = W <= 16;  // 32-wide tiles would be half empty
-  // 8-wave 256 ch x 256 px tiles run ~10-15 % faster per FLOP than 4-wave 128 x 128 tiles on
-  // layers with >= 256 output channels (measured), unless their coarser pixel tiling wastes more
-  // than that on the map's ragged edge (e.g. 68x120) or the map is narrow.
+  // 8-wave 256 ch x 256 px tiles run ~10 % faster per FLOP than 4-wave 128 x 128 tiles on layers
+  // with >= 256 output channels (measured), unless their coarser pixel tiling wastes more than half
+  // of that on the map's ragged edge (e.g. 68x120) or the map is narrow.  (An 8-wave 128 ch x 256 px
+  // tile for the 128-channel layers measured 5-9 % SLOWER than the 4-wave tile.)
   bool big = g_conv_variant == 1 && cs.cout >= 256 && !narrow;
   if (big) {
     const double eff_big = (double)H * W / ((double)cdiv(W, 32) * cdiv(H, 8) * 256.0);
     const double eff_small = (double)H * W / ((double)cdiv(W, 32) * cdiv(H, 4) * 128.0);
-    big = eff_big * 1.12 >= eff_small;
+    big = eff_big * 1.05 >= eff_small;
   }
 #define NQA_GO(WN, WM, TN, TM)                                                                           \
   return narrow ? launch_igemm<P, WN, WM, TN, TM, 16>(in, n, H, W, cs.cin, cs.cout, wpk, bias, out, st) \
