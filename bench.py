@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="256")
     ap.add_argument("--precision", default=None, help="f16 (default), f32, bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch", type=int, default=0, help="override pairs per GPU per step (experiments only)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -117,7 +118,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     wl = WORKLOADS[args.workload]
-    B, H, W = wl["B"], wl["H"], wl["W"]
+    B, H, W = args.batch or wl["B"], wl["H"], wl["W"]
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         model = DISTS(precision=args.precision).to(dev).eval()

@@ -57,6 +57,53 @@ def test_conv1_1(prec, shape, np_convs, packed, dev):
     _close(got, ref, OUT_RTOL[prec], f"conv1_1[{prec}]")
 
 
+@pytest.mark.parametrize("prec", ["f16", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 3, 37, 53), (1, 3, 16, 16), (3, 3, 5, 70), (1, 3, 64, 96), (2, 3, 9, 33)])
+def test_conv1_fused(prec, shape, np_convs, packed, dev):
+    """Stage 1 in one kernel (conv1_1 on MFMA feeding conv1_2 through LDS) == the two oracle convs.
+
+    conv1_1's inputs and weights are rounded to 16 bits here (they are fp32 in the two-kernel
+    path), so the bound is the two-layer accumulation of 16-bit rounding, not a single rounding.
+    """
+    from nerf_qa_amd import ops
+    x = _rand(shape, 21)
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    w0, b0 = torch.from_numpy(np_convs[0][0]), torch.from_numpy(np_convs[0][1])
+    w1, b1 = torch.from_numpy(np_convs[1][0]), torch.from_numpy(np_convs[1][1])
+    ref = F.relu(F.conv2d(F.relu(F.conv2d((x - mean) / std, w0, b0, padding=1)), w1, b1, padding=1))
+    out = ops.conv1_fused(x.to(dev), packed[prec], prec)
+    assert out.dtype == DT[prec] and out.shape == (shape[0], shape[2], shape[3], 64)
+    got = out.float().permute(0, 3, 1, 2).cpu()
+    _close(got, ref, 3 * OUT_RTOL[prec], f"conv1_fused[{prec}] {shape}")
+
+
+def test_conv1_fused_rejects_f32(packed, dev):
+    from nerf_qa_amd import NqaError, ops
+    with pytest.raises(NqaError):
+        ops.conv1_fused(torch.zeros(1, 3, 8, 8, device=dev), packed["f32"], "f32")
+
+
+def test_pool_stats_matches_separate_kernels(packed, alpha_beta, dev):
+    """The fused pool+statistics pass (taps 1..4 of the DISTS path) against the stand-alone L2-pool:
+    run the pyramid op by op with nqa_l2pool and compare the taps with nqa_vgg_pyramid's."""
+    from nerf_qa_amd import ops, synth
+    x, _ = synth.frame_batch([3], 45, 70)
+    x = torch.from_numpy(x).to(dev)
+    prec = "f16"
+    taps = ops.vgg_pyramid(x, packed[prec], prec)
+    h = ops.conv1_fused(x, packed[prec], prec)
+    layer = 2
+    for k in range(5):
+        assert torch.equal(h, taps[k]), f"tap {k + 1} differs"
+        if k == 4:
+            break
+        h = ops.l2pool(h, prec)
+        for _ in range((2, 2, 3, 3, 3)[k + 1]):
+            h = ops.conv3x3_relu(h, layer, packed[prec], prec)
+            layer += 1
+
+
 CONV_CASES = [  # (layer, n, H, W)
     (1, 2, 13, 37), (1, 1, 32, 64), (1, 2, 9, 16),
     (2, 2, 11, 40), (3, 1, 8, 33), (3, 3, 16, 16), (4, 1, 7, 7),
