@@ -148,7 +148,15 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void conv3x3_igemm_kernel(
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
-  const int bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so workgroup ids that
+  // are equal mod 8 share an L2.  Give each of those classes a contiguous run of pixel tiles so
+  // that neighbouring tiles' halo overlap is an L2 hit (speed only; any placement is correct).
+  int tile_id = blockIdx.x;
+  {
+    const int nb = gridDim.x, qq = nb >> 3, rr = nb & 7, xcd = tile_id & 7, local = tile_id >> 3;
+    tile_id = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + local;
+  }
+  const int bx = tile_id % tiles_x, by = tile_id / tiles_x;
   const int n = blockIdx.y, ct = blockIdx.z;
   const int x0 = bx * TW, y0 = by * G::TH;
   const int wn = wave % WAVES_N, wm = wave / WAVES_N;
