@@ -417,31 +417,35 @@ __global__ __launch_bounds__(512) void conv1_fused_kernel(const float *__restric
     const int row = i / 108, rem = i - row * 108, col = rem / 3;
     r_plan[r] = i < 432 ? (row << 16 | col << 2 | (rem - col * 3)) : -1;
   }
-  auto fetch = [&](int tile, int pt, float(&rv)[7], unsigned &okmask) {
-    int n, x0, y0;
-    tile_coords(tile, n, x0, y0);
+  // per-lane part of a raw pixel's address, fixed for the whole kernel: c*HW + row*W + col
+  int r_off[7];
+#pragma unroll
+  for (int r = 0; r < 7; ++r) {
+    const int row = r_plan[r] >> 16, col = (r_plan[r] >> 2) & 0x3FFF, c = r_plan[r] & 3;
+    r_off[r] = c * HW + row * W + col;
+  }
+  auto fetch = [&](int n, int x0, int y0, int pt, float(&rv)[7], unsigned &okmask) {
     const float *img = (n < B ? x + (size_t)n * 3 * HW : y + (size_t)(n - B) * 3 * HW);
     const int r0 = (pt * 32) / G::HW_;  // first halo row this column tile touches
+    const int gy0 = y0 - 2 + r0, gx0 = x0 - 2;
+    const float *org = img + (gy0 * W + gx0);  // may point before the image: only dereferenced when ok
     okmask = 0;
 #pragma unroll
     for (int r = 0; r < 7; ++r) {
-      const int row = r_plan[r] >> 16, col = (r_plan[r] >> 2) & 0x3FFF, c = r_plan[r] & 3;
-      const int gy = y0 - 2 + r0 + row, gx = x0 - 2 + col;
-      const bool ok = r_plan[r] >= 0 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      const int row = r_plan[r] >> 16, col = (r_plan[r] >> 2) & 0x3FFF;
+      const bool ok = r_plan[r] >= 0 && (unsigned)(gy0 + row) < (unsigned)H && (unsigned)(gx0 + col) < (unsigned)W;
       rv[r] = 0.f;
 #ifndef NQA_F_NO_FETCH
-      if (ok) rv[r] = img[(size_t)c * HW + gy * W + gx];
+      if (ok) rv[r] = org[r_off[r]];
 #endif
       okmask |= ok ? (1u << r) : 0u;
     }
   };
-  auto finish = [&](int tile, int pt, const float(&rv)[7], unsigned okmask) {
+  auto finish = [&](int x0, int y0, int pt, const float(&rv)[7], unsigned okmask) {
 #ifdef NQA_F_NO_P1
     asm volatile("" ::"v"(rv[0]), "v"(rv[1]), "v"(rv[2]), "v"(rv[3]), "v"(rv[4]), "v"(rv[5]), "v"(rv[6]), "v"(okmask));
     return;
 #endif
-    int n, x0, y0;
-    tile_coords(tile, n, x0, y0);
     const int r0 = (pt * 32) / G::HW_;
 #pragma unroll
     for (int r = 0; r < 7; ++r) {
@@ -493,13 +497,17 @@ __global__ __launch_bounds__(512) void conv1_fused_kernel(const float *__restric
   const bool hasB = w4 + 4 < F::NPT;
   // raw pixels of both of this wave's column tiles of `tile` -> registers (no wait)
   auto fetch_both = [&](int tile) {
-    fetch(tile, w4, rawA, okA);
-    if (hasB) fetch(tile, w4 + 4, rawB, okB);
+    int n, x0, y0;
+    tile_coords(tile, n, x0, y0);
+    fetch(n, x0, y0, w4, rawA, okA);
+    if (hasB) fetch(n, x0, y0, w4 + 4, rawB, okB);
   };
   // precondition: fetch_both(tile) was issued (a phase earlier, so the loads have landed)
   auto phase1 = [&](int tile) {
-    finish(tile, w4, rawA, okA);
-    if (hasB) finish(tile, w4 + 4, rawB, okB);
+    int n, x0, y0;
+    tile_coords(tile, n, x0, y0);
+    finish(x0, y0, w4, rawA, okA);
+    if (hasB) finish(x0, y0, w4 + 4, rawB, okB);
   };
 
   // ---- P2: conv1_2 of the group's tile; wave w4 owns tile row w4 ----
