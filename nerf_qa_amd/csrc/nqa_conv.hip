@@ -146,7 +146,10 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void conv3x3_igemm_kernel(
   typedef ConvGeom<WAVES_N, WAVES_M, WN_T, WM_T, TW> G;
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [A0][A1][W0][W1]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // the wave index as a provably wave-uniform (SGPR) value: every LDS-DMA destination is then
+  // scalar arithmetic + s_mov m0 instead of a VGPR address + v_readfirstlane per DMA
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, h = lane >> 5;
   // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so workgroup ids that
   // are equal mod 8 share an L2.  Give each of those classes a contiguous run of pixel tiles so
