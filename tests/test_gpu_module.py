@@ -108,3 +108,59 @@ def test_refuses_cpu_and_require_grad(model, dev):
         model(x.to(dev), y.to(dev), require_grad=True)
     with pytest.raises(ValueError):
         model(x.to(dev), y[:, :, :16].to(dev))
+
+
+def test_original_and_softmax_variants(model, oracle_convs, dev):
+    """DISTS_pt_original (0-d for B=1, clamped alpha/beta) and DISTS_pt_softmax agree with the
+    canonical score when their weight transforms are identities."""
+    import pandas as pd  # noqa: F401
+    from nerf_qa_amd import config as cfgmod
+    from nerf_qa_amd.DISTS_pytorch.DISTS_pt_original import DISTS as DO
+    from nerf_qa_amd.DISTS_pytorch.DISTS_pt_softmax import DISTS as DS
+    cfg = cfgmod.config()
+    cfg.weight_lower_bound, cfg.alpha_beta_ratio, cfg.dists_weight_norm, cfg.detach_beta = 0.0, 1.0, "off", "False"
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        mo, ms = DO().to(dev).eval(), DS().to(dev).eval()
+    x, y = _pair(64, 64, seeds=(11, 12))
+    x, y = x.to(dev), y.to(dev)
+    with torch.no_grad():
+        ref = model(x, y)
+        a = mo(x, y)
+        b = ms(x, y)
+        one = mo(x[:1], y[:1])
+    assert a.shape == (2,) and one.dim() == 0
+    assert (a - ref).abs().max().item() < 2e-6
+    assert (b - ref).abs().max().item() < 2e-5          # softmax(log(w + 1e-10)) reproduces w to ~1e-7
+    assert mo.original_alpha.device == x.device
+    # options: relu + detach_beta leave a graph to alpha only
+    cfg.dists_weight_norm, cfg.detach_beta = "relu+w_sum_detach", "True"
+    s = mo(x, y).sum()
+    mo.zero_grad()
+    s.backward()
+    assert mo.alpha.grad is not None and (mo.beta.grad is None or float(mo.beta.grad.abs().sum()) == 0.0)
+    cfg.dists_weight_norm, cfg.detach_beta = "off", "False"
+
+
+def test_nerfqa_model_head(dev):
+    import pandas as pd
+    from nerf_qa_amd import config as cfgmod
+    from nerf_qa_amd.model_stats import NeRFQAModel
+    cfg = cfgmod.config()
+    rng = np.random.default_rng(0)
+    d = rng.uniform(0.05, 0.4, 40)
+    df = pd.DataFrame({"DISTS": d, "MOS": 5 - 8 * d + 0.01 * rng.standard_normal(40)})
+    x, y = _pair(48, 48, seeds=(1, 2))
+    for kind in ("linear", "sqrt", "logistic"):
+        cfg.regression_type = kind
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m = NeRFQAModel(df).to(dev)
+        scores, dists_scores = m(x.to(dev), y.to(dev))
+        assert scores.shape == dists_scores.shape == (2,)
+        assert torch.isfinite(scores).all()
+        (scores.sum() + 1e-3 * m.entropy_loss()).backward()
+        assert m.dists_model.alpha.grad is not None
+        if kind == "linear":
+            assert abs(m.dists_weight.item() + 8) < 0.5 and abs(m.dists_bias.item() - 5) < 0.2
+    cfg.regression_type = "linear"
