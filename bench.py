@@ -32,8 +32,12 @@ from nerf_qa_amd import ops, sharding, synth  # noqa: E402
 from nerf_qa_amd.DISTS_pytorch import DISTS  # noqa: E402
 
 WORKLOADS = {
-    "256": dict(name="configs[1]: B=32 256x256 synthetic frame pairs per GPU", B=32, H=256, W=256),
-    "1080p": dict(name="configs[2]: B=8 1920x1080 synthetic frame pairs per GPU", B=8, H=1080, W=1920),
+    "256": dict(name="configs[1]: B=32 256x256 synthetic frame pairs per GPU", B=32, H=256, W=256, metric="DISTS"),
+    "1080p": dict(name="configs[2]: B=8 1920x1080 synthetic frame pairs per GPU", B=8, H=1080, W=1920, metric="DISTS"),
+    "adists1080p": dict(name="configs[4]: A-DISTS, B=8 1920x1080 synthetic frame pairs per GPU", B=8, H=1080, W=1920,
+                        metric="A-DISTS"),
+    "adists256": dict(name="A-DISTS, B=32 256x256 synthetic frame pairs per GPU", B=32, H=256, W=256,
+                      metric="A-DISTS"),
 }
 PEAK_TFLOPS = {"f16": 2500.0, "bf16": 2500.0, "f32": 157.3}  # dense MFMA, MI355X_MICROARCH.md
 
@@ -61,25 +65,29 @@ def host_cores():
     return n
 
 
-def cpu_baseline(h, w, budget_s=20.0):
+def cpu_baseline(h, w, budget_s=20.0, adists=False):
     """The oracle (kind "port") on the host cores: frame-pairs/s on a bounded sample."""
-    from oracle import dists_oracle
+    from oracle import adists_oracle, dists_oracle
     cores = host_cores()
     torch.set_num_threads(cores)
     convs = dists_oracle.convs_from_numpy(synth.vgg16_weights(1234))
     ab = DISTS_alpha_beta()
+    if adists:
+        run = lambda a, b: adists_oracle.adists(a, b, convs)  # noqa: E731
+    else:
+        run = lambda a, b: dists_oracle.dists(a, b, convs, *ab)  # noqa: E731
     # size the sample from one warm-up pair so the whole leg stays near the budget
     xn, yn = synth.frame_batch([0], h, w)
     x1, y1 = torch.from_numpy(xn), torch.from_numpy(yn)
     t0 = time.perf_counter()
-    dists_oracle.dists(x1, y1, convs, *ab)
+    run(x1, y1)
     t_one = time.perf_counter() - t0
     n = max(1, min(8, int(budget_s / 3.0 / max(t_one, 1e-3))))
     x, y = x1.repeat(n, 1, 1, 1), y1.repeat(n, 1, 1, 1)
     times = []
     for _ in range(3):
         t0 = time.perf_counter()
-        dists_oracle.dists(x, y, convs, *ab)
+        run(x, y)
         times.append(time.perf_counter() - t0)
         if sum(times) > budget_s:
             break
@@ -98,7 +106,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="256")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="256",
+                    help="256 (default, BASELINE configs[1]) | 1080p | adists1080p | adists256")
     ap.add_argument("--precision", default=None, help="f16 (default), f32, bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=0, help="override pairs per GPU per step (experiments only)")
@@ -128,7 +137,13 @@ def main():
     B, H, W = args.batch or wl["B"], wl["H"], wl["W"]
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        model = DISTS(precision=args.precision).to(dev).eval()
+        if wl["metric"] == "A-DISTS":
+            from nerf_qa_amd.ADISTS import ADISTS
+            net = ADISTS(precision=args.precision).to(dev).eval()
+            model = lambda a, b: net(a, b, as_loss=False)  # noqa: E731  (x = reference frame drives ps / weights)
+            model.precision, model.vgg_source = net.precision, net.vgg_source
+        else:
+            model = DISTS(precision=args.precision).to(dev).eval()
     prec = model.precision
 
     # synthetic frames generated on the device (no host I/O in the timed region); each rank
@@ -174,7 +189,7 @@ def main():
         achieved = (ig_flops * 2 * B * steps_timed) / (ms_ig * 1e-3) / 1e12 if ms_ig > 0 else None
         peak = PEAK_TFLOPS[prec]
         out = {
-            "metric": "DISTS frame-pairs/s",
+            "metric": wl["metric"] + " frame-pairs/s",
             "value": round(world * B * args.steps / dt, 2),
             "unit": "frame-pairs/s",
             "n_gpus": world,
@@ -198,7 +213,7 @@ def main():
             "kernel_ms_per_step": {k: round(v[1] / max(steps_timed, 1), 4) for k, v in ktimes.items() if v[0]},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(H, W)
+            out["cpu_baseline"] = cpu_baseline(H, W, adists=wl["metric"] == "A-DISTS")
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
