@@ -116,6 +116,22 @@ __global__ __launch_bounds__(256) void conv1_1_kernel(const float *__restrict__ 
 // stage: vmcnt(0) + barrier retires stage s while stage s+1 is already in flight.
 typedef __attribute__((address_space(3))) void lds_void_t;
 
+#ifdef NQA_STAMPS  // diagnostic build: per-segment shader-cycle sums of the stage loop (never shipped)
+__device__ unsigned long long g_stamps[8];
+__device__ inline unsigned long long stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define NQA_STAMP(var) const unsigned long long var = stamp()
+#define NQA_STAMP_ADD(seg, a, b) seg_sum[seg] += (b) - (a)
+#else
+#define NQA_STAMP(var)
+#define NQA_STAMP_ADD(seg, a, b)
+#endif
+
 template <int WAVES_N, int WAVES_M, int WN_T, int WM_T, int TW>
 struct ConvGeom {
   static constexpr int THREADS = 64 * WAVES_N * WAVES_M;
@@ -249,12 +265,22 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void conv3x3_igemm_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+#ifdef NQA_STAMPS
+  unsigned long long seg_sum[4] = {0, 0, 0, 0};
+#endif
   issue(0);
   for (int s = 0; s < S; ++s) {
     const int cc = s / 3, ky = s - cc * 3;
+    NQA_STAMP(t0);
     dma_wait();       // this wave's DMA for stage s has landed
+    NQA_STAMP(t1);
     __syncthreads();  // ... and everyone's; every wave has also finished reading stage s-1
+    NQA_STAMP(t2);
     if (s + 1 < S) issue(s + 1);
+    NQA_STAMP(t3);
+    NQA_STAMP_ADD(0, t0, t1);
+    NQA_STAMP_ADD(1, t1, t2);
+    NQA_STAMP_ADD(2, t2, t3);
     const char *abuf = smem + (cc & 1) * G::A_BYTES;
     const char *wbuf = smem + (s & 1) * G::W_BYTES;
     // six k-steps per stage (3 taps x 2 chunk pairs); fragments of step t+1 are read from LDS
@@ -298,7 +324,15 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void conv3x3_igemm_kernel(
       mma_all(afB, bfB);
       __builtin_amdgcn_sched_barrier(0);
     }
+    NQA_STAMP(t4);
+    NQA_STAMP_ADD(3, t3, t4);
   }
+#ifdef NQA_STAMPS
+  if (lane == 0) {
+    for (int i = 0; i < 4; ++i) atomicAdd(&g_stamps[i], seg_sum[i]);
+    atomicAdd(&g_stamps[4], (unsigned long long)S);
+  }
+#endif
 
   // ---- epilogue: bias + ReLU, 4 consecutive output channels per lane per store ----
   // acc[i][j][r]: channel = 8*(r>>2) + 4*h + (r&3) of row tile i, pixel = lane&31 of column tile j.
@@ -625,6 +659,17 @@ __global__ __launch_bounds__(512) void conv1_fused_kernel(const float *__restric
 // ---------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------
+#ifdef NQA_STAMPS
+extern "C" int nqa_debug_stamps(unsigned long long *out8, int reset) {
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_stamps), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[8] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
+
 static int g_conv_variant = 1;  // 0: 4-wave tiles everywhere; 1: 8-wave tiles where the layer is wide enough
 void set_conv_variant(int v) { g_conv_variant = v; }
 
