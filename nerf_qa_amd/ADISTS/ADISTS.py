@@ -7,6 +7,12 @@ Mirrors nerf_qa/ADISTS/ADISTS.py:
 Asymmetric like the reference: texture probabilities and entropy weights come from x
 only (:147,153), so callers pass x = reference frame (prep.py:186).
 
+Precision: the default here is "f32" (exact-f32 MFMA convolutions, 1e-7 from the reference).
+A-DISTS min-max-normalises a sigmoid of a z-scored variance/mean ratio (:82-90); on some inputs
+(seen on blurred frames) that chain amplifies the 2^-11 rounding of 16-bit features to 3-5e-4 in
+the score, which breaks the 1e-4 bar DISTS' smooth statistics keep with margin.  precision="f16"
+is the opt-in fast mode (2.2x the throughput at 1080p).
+
 as_loss=True in the reference runs the pyramids WITH autograd (:139-141); this build has
 no VGG backward, so the value 1-mean(D) is returned without a graph.  as_map=True (the
 [B,B,H,W] distortion map, :188-193) is outside the hot path and raises.
@@ -21,7 +27,9 @@ import torch.nn as nn
 
 from .. import ops
 from .._lib import prec_id
-from ..DISTS_pytorch.DISTS_pt import DEFAULT_PRECISION, L2pooling as Downsample, _build_stages  # noqa: F401
+from ..DISTS_pytorch.DISTS_pt import L2pooling as Downsample, _build_stages  # noqa: F401
+
+DEFAULT_PRECISION = "f32"
 from ..vgg_weights import load_vgg16_convs
 
 
@@ -42,7 +50,7 @@ class ADISTS(torch.nn.Module):
         self.window_size = window_size
         for k in range(len(self.chns)):
             self.windows.append(self.create_window(self.window_size, self.window_size / 3, self.chns[k]))
-        self.precision = precision or os.environ.get("NQA_PRECISION", DEFAULT_PRECISION)
+        self.precision = precision or os.environ.get("NQA_ADISTS_PRECISION", DEFAULT_PRECISION)
         prec_id(self.precision)
         self._packed = None
         self._packed_key = None

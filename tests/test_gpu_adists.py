@@ -10,6 +10,9 @@ from conftest import GOLDEN
 
 pytestmark = pytest.mark.gpu
 ADISTS_GOLD = sorted(glob.glob(os.path.join(GOLDEN, "adists_*.npz")))
+# f32 is the A-DISTS default and is held to the 1e-4 bar (it lands at 1e-7).  f16 measures <= 1.1e-5
+# on these goldens but up to 4.7e-4 on some blurred frames (tests/test_gpu_fullsize.py), so it is an
+# opt-in mode; bf16 likewise.
 SCORE_TOL = {"f32": 1e-4, "f16": 1e-4, "bf16": 1e-3}
 
 

@@ -1,0 +1,104 @@
+"""Parity at BASELINE.json's full sizes through size-independent properties (GPU box only).
+
+The CPU oracle needs minutes per 1080p pair, so at full size the HIP path is held to what the
+algorithm guarantees regardless of size: identical inputs score 0, DISTS is symmetric in (x, y), a
+pair's score does not depend on its batch neighbours, and the default f16 path agrees with the
+exact-f32 MFMA path (itself pinned to the oracle at 1e-7 on the golden sizes) within the 1e-4 bar.
+"""
+import warnings
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def models(dev):
+    from nerf_qa_amd.ADISTS import ADISTS
+    from nerf_qa_amd.DISTS_pytorch import DISTS
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = {"f16": DISTS(precision="f16").to(dev).eval(), "f32": DISTS(precision="f32").to(dev).eval(),
+             "a16": ADISTS(precision="f16").to(dev).eval(), "a32": ADISTS(precision="f32").to(dev).eval()}
+        assert DISTS().precision == "f16" and ADISTS().precision == "f32"  # the shipped defaults
+        return m
+
+
+def _frames(b, h, w, dev, seed):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    x = torch.rand(b, 3, h, w, device=dev, generator=g)
+    # a smooth low-frequency component so that blur / noise change structure, not only texture
+    yy = torch.linspace(0, 12.0, h, device=dev).view(1, 1, h, 1)
+    xx = torch.linspace(0, 17.0, w, device=dev).view(1, 1, 1, w)
+    x = (0.6 * x + 0.4 * (0.5 + 0.5 * torch.sin(xx) * torch.cos(yy))).clamp_(0, 1)
+    y = x.clone()
+    y[0::2] = (x[0::2] + 0.1 * torch.randn(x[0::2].shape, device=dev, generator=g)).clamp_(0, 1)
+    y[1::2] = torch.nn.functional.avg_pool2d(x[1::2], 5, stride=1, padding=2)
+    return x, y
+
+
+@pytest.mark.parametrize("b,h,w", [(32, 256, 256), (4, 1080, 1920)], ids=["B32_256", "B4_1080p"])
+def test_dists_full_size_properties(b, h, w, models, dev):
+    x, y = _frames(b, h, w, dev, 7)
+    with torch.no_grad():
+        s16 = models["f16"](x, y)
+        s32 = models["f32"](x, y)
+        assert s16.shape == (b,) and torch.isfinite(s16).all()
+        # f16 path vs exact-f32 path
+        d = (s16 - s32).abs().max().item()
+        print(f"\nDISTS {b}x{h}x{w}: score range [{s32.min().item():.4f}, {s32.max().item():.4f}] |f16-f32|={d:.2e}")
+        assert d <= 1e-4
+        # identical inputs -> 0
+        assert models["f16"](x[:2], x[:2].clone()).abs().max().item() < 2e-6
+        # symmetry
+        assert (models["f16"](y, x) - s16).abs().max().item() < 2e-6
+        # batch independence (pair 1 alone; a different grid / statistics split)
+        alone = models["f16"](x[1:2], y[1:2])
+        assert abs(alone.item() - s16[1].item()) < 2e-6
+        # batch_average is the mean of the per-pair scores
+        assert abs(models["f16"](x, y, batch_average=True).item() - s16.mean().item()) < 1e-6
+
+
+@pytest.mark.parametrize("b,h,w", [(8, 256, 256), (2, 1080, 1920)], ids=["B8_256", "B2_1080p"])
+def test_adists_full_size_properties(b, h, w, models, dev):
+    x, y = _frames(b, h, w, dev, 11)
+    with torch.no_grad():
+        a16 = models["a16"](x, y, as_loss=False)
+        a32 = models["a32"](x, y, as_loss=False)
+        d = (a16 - a32).abs().max().item()
+        print(f"\nA-DISTS {b}x{h}x{w}: score range [{a32.min().item():.4f}, {a32.max().item():.4f}] |f16-f32|={d:.2e}")
+        # the opt-in f16 mode: A-DISTS' min-max / sigmoid chain amplifies 16-bit feature rounding on some
+        # (blurred) inputs to a few 1e-4 -- the reason its default is f32; held to 1e-3 here
+        assert torch.isfinite(a16).all() and d <= 1e-3
+        for key in ("a32", "a16"):
+            full = models[key](x, y, as_loss=False)
+            assert models[key](x[:1], x[:1].clone(), as_loss=False).abs().max().item() < 1e-5
+            alone = models[key](x[1:2], y[1:2], as_loss=False)
+            assert abs(alone.item() - full[1].item()) < 2e-6
+            assert abs(models[key](x, y).item() - full.mean().item()) < 1e-6
+
+
+@pytest.mark.parametrize("h,w", [(5, 7), (16, 16), (17, 300), (1, 40), (33, 2)])
+def test_small_and_ragged_sizes_vs_oracle(h, w, models, oracle_convs, dev):
+    """Sizes where every tile is ragged and late stages collapse to 1-2 pixels, against the oracle."""
+    from nerf_qa_amd import synth
+    from oracle import adists_oracle, dists_oracle
+    xn, yn = synth.frame_batch([70, 71], h, w)
+    x, y = torch.from_numpy(xn), torch.from_numpy(yn)
+    m = models["f32"]
+    ref = dists_oracle.dists(x, y, oracle_convs, m.alpha.detach().cpu(), m.beta.detach().cpu())
+    aref = adists_oracle.adists(x, y, oracle_convs)
+    with torch.no_grad():
+        for key, tol in (("f32", 5e-6), ("f16", 1e-4)):
+            got = models[key](x.to(dev), y.to(dev)).cpu()
+            assert (got - ref).abs().max().item() <= tol, (key, got, ref)
+        for key, tol in (("a32", 2e-5), ("a16", 1e-3)):
+            got = models[key](x.to(dev), y.to(dev), as_loss=False).cpu()
+            assert (got - aref).abs().max().item() <= tol, (key, got, aref)
