@@ -39,7 +39,8 @@ WORKLOADS = {
     "adists256": dict(name="A-DISTS, B=32 256x256 synthetic frame pairs per GPU", B=32, H=256, W=256,
                       metric="A-DISTS"),
 }
-PEAK_TFLOPS = {"f16": 2500.0, "bf16": 2500.0, "f32": 157.3}  # dense MFMA, MI355X_MICROARCH.md
+PEAK_TFLOPS = {"f16": 2500.0, "bf16": 2500.0, "f32": 157.3,  # dense MFMA, MI355X_MICROARCH.md
+               "f32s": 2500.0 / 3}  # split-f16: three half MFMAs per algorithmic product
 
 
 def conv_flops_per_image(h, w):
@@ -108,7 +109,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="256",
                     help="256 (default, BASELINE configs[1]) | 1080p | adists1080p | adists256")
-    ap.add_argument("--precision", default=None, help="f16 (default), f32, bf16")
+    ap.add_argument("--precision", default=None, help="f16 (DISTS default), f32 (A-DISTS default), f32s, bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=0, help="override pairs per GPU per step (experiments only)")
     args = ap.parse_args()

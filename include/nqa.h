@@ -21,8 +21,8 @@
  * Layouts
  *   - images enter as the reference's tensors: float32 NCHW, values in [0,1];
  *   - activations inside the pyramid are NHWC in the element type of the chosen
- *     precision (`prec`): NQA_PREC_F32 float, NQA_PREC_BF16 bfloat16, NQA_PREC_F16
- *     IEEE half.  All accumulation and all statistics are float32/float64;
+ *     precision (`prec`): NQA_PREC_F32 / NQA_PREC_F32S float, NQA_PREC_BF16 bfloat16,
+ *     NQA_PREC_F16 IEEE half.  All accumulation and all statistics are float32/float64;
  *   - VGG weights are handed over once as a packed blob (nqa_pack_vgg_weights).
  */
 #ifndef NQA_H
@@ -37,7 +37,10 @@ extern "C" {
 
 #define NQA_VERSION 1
 
-enum { NQA_PREC_F32 = 0, NQA_PREC_BF16 = 1, NQA_PREC_F16 = 2 };
+/* NQA_PREC_F32S: float32 activations like NQA_PREC_F32, but conv layers 2..13 multiply on the f16
+ * matrix cores with both operands split into (hi, lo) half pairs (3 MFMAs per product block,
+ * ~2^-21 relative error per product) -- near-f32 results at a fraction of the f32-MFMA cost. */
+enum { NQA_PREC_F32 = 0, NQA_PREC_BF16 = 1, NQA_PREC_F16 = 2, NQA_PREC_F32S = 3 };
 
 enum {
   NQA_OK = 0,

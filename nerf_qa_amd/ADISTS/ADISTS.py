@@ -7,11 +7,13 @@ Mirrors nerf_qa/ADISTS/ADISTS.py:
 Asymmetric like the reference: texture probabilities and entropy weights come from x
 only (:147,153), so callers pass x = reference frame (prep.py:186).
 
-Precision: the default here is "f32" (exact-f32 MFMA convolutions, 1e-7 from the reference).
-A-DISTS min-max-normalises a sigmoid of a z-scored variance/mean ratio (:82-90); on some inputs
-(seen on blurred frames) that chain amplifies the 2^-11 rounding of 16-bit features to 3-5e-4 in
-the score, which breaks the 1e-4 bar DISTS' smooth statistics keep with margin.  precision="f16"
-is the opt-in fast mode (2.2x the throughput at 1080p).
+Precision: the default here is "f32s": float32 activations, convolutions on the f16 matrix cores
+with both operands split into (hi, lo) half pairs (3 MFMAs per product) -- 1e-7 from the exact-f32
+path and from the reference, at ~1.9x the exact-f32 ("f32") throughput.  Plain 16-bit features are
+NOT safe for A-DISTS: it min-max-normalises a sigmoid of a z-scored variance/mean ratio (:82-90),
+and on some inputs that chain amplifies the 2^-11 rounding of f16 weights or activations to 3-5e-4
+in the score, which breaks the 1e-4 bar DISTS' smooth statistics keep with margin.
+precision="f16" stays available as the opt-in fast mode (3x the throughput at 1080p).
 
 as_loss=True in the reference runs the pyramids WITH autograd (:139-141); this build has
 no VGG backward, so the value 1-mean(D) is returned without a graph.  as_map=True (the
@@ -29,7 +31,7 @@ from .. import ops
 from .._lib import prec_id
 from ..DISTS_pytorch.DISTS_pt import L2pooling as Downsample, _build_stages  # noqa: F401
 
-DEFAULT_PRECISION = "f32"
+DEFAULT_PRECISION = "f32s"
 from ..vgg_weights import load_vgg16_convs
 
 

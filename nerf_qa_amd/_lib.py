@@ -13,9 +13,10 @@ import torch  # noqa: F401  (loads the HIP runtime the library binds to; must co
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NQA_LIB") or os.path.join(_HERE, "libnqa_hip.so")  # NQA_LIB: development builds only
 
-PREC_F32, PREC_BF16, PREC_F16 = 0, 1, 2
-PREC_NAMES = {"f32": PREC_F32, "fp32": PREC_F32, "bf16": PREC_BF16, "f16": PREC_F16, "fp16": PREC_F16}
-PREC_DTYPE = {PREC_F32: torch.float32, PREC_BF16: torch.bfloat16, PREC_F16: torch.float16}
+PREC_F32, PREC_BF16, PREC_F16, PREC_F32S = 0, 1, 2, 3
+PREC_NAMES = {"f32": PREC_F32, "fp32": PREC_F32, "bf16": PREC_BF16, "f16": PREC_F16, "fp16": PREC_F16,
+              "f32s": PREC_F32S}
+PREC_DTYPE = {PREC_F32: torch.float32, PREC_BF16: torch.bfloat16, PREC_F16: torch.float16, PREC_F32S: torch.float32}
 NUM_CONVS, NUM_TAPS, TOTAL_CHNS = 13, 6, 1475
 K_NAMES = ("conv1_1", "conv_igemm", "l2pool", "stats", "adists")
 

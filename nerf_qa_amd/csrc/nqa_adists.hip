@@ -803,7 +803,7 @@ int nqa_adists_forward(const float *x, const float *y, int B, int H, int W, cons
     set_error("adists_forward: null pointer");
     return NQA_E_ARG;
   }
-  if (B <= 0 || H <= 0 || W <= 0 || (prec != NQA_PREC_F32 && prec != NQA_PREC_BF16 && prec != NQA_PREC_F16)) {
+  if (B <= 0 || H <= 0 || W <= 0 || !prec_valid(prec)) {
     set_error("adists_forward: bad size or prec (B=%d H=%d W=%d prec=%d)", B, H, W, prec);
     return NQA_E_ARG;
   }
@@ -831,7 +831,7 @@ int nqa_adists_forward(const float *x, const float *y, int B, int H, int W, cons
 
   // ---- pyramids (x images [0,B), y images [B,2B)) with the global statistics per tap ----
   if ((rc = stats_nchw(x, y, B, 3, H * W, part + p.sd.part_off[0], st))) return rc;
-  const bool fused1 = prec != NQA_PREC_F32;
+  const bool fused1 = prec_elem_bytes(prec) == 2;
   if (!fused1) {
     if ((rc = conv1_1(x, B, H, W, packed, prec, base + p.bufA, st))) return rc;
     if ((rc = conv1_1(y, B, H, W, packed, prec, base + p.bufA + (size_t)B * H * W * 64 * esz, st))) return rc;
@@ -886,7 +886,7 @@ int nqa_adists_forward(const float *x, const float *y, int B, int H, int W, cons
     const int hw = p.h[k] * p.w[k];
     const float *invx = q + 0 * qst + p.sd.coff[k], *sumx = q + 2 * qst + p.sd.coff[k];
     double *ep = ent + p.ed.part_off[k];
-    switch (prec) {
+    switch (storage_prec(prec)) {
       case NQA_PREC_F32: rc = launch_entropy<PrecF32>(taps[k - 1], B, hw, p.c[k], p.ent_ppb[k], invx, sumx, ctot, ep, st); break;
       case NQA_PREC_BF16: rc = launch_entropy<PrecBF16>(taps[k - 1], B, hw, p.c[k], p.ent_ppb[k], invx, sumx, ctot, ep, st); break;
       default: rc = launch_entropy<PrecF16>(taps[k - 1], B, hw, p.c[k], p.ent_ppb[k], invx, sumx, ctot, ep, st); break;
@@ -927,7 +927,7 @@ int nqa_adists_forward(const float *x, const float *y, int B, int H, int W, cons
     } else {
       const char *tx = static_cast<const char *>(taps[k - 1]);
       const char *ty = tx + (size_t)B * p.h[k] * p.w[k] * p.c[k] * esz;
-      switch (prec) {
+      switch (storage_prec(prec)) {
         case NQA_PREC_F32: rc = launch_window_lanes<PrecF32>(tx, ty, B, p.h[k], p.w[k], p.c[k], q, ctot, p.sd.coff[k], wgt, gauss, g2, gamma, tw, sw, st); break;
         case NQA_PREC_BF16: rc = launch_window_lanes<PrecBF16>(tx, ty, B, p.h[k], p.w[k], p.c[k], q, ctot, p.sd.coff[k], wgt, gauss, g2, gamma, tw, sw, st); break;
         default: rc = launch_window_lanes<PrecF16>(tx, ty, B, p.h[k], p.w[k], p.c[k], q, ctot, p.sd.coff[k], wgt, gauss, g2, gamma, tw, sw, st); break;

@@ -1,6 +1,7 @@
 // extern "C" surface of libnqa_hip.so (include/nqa.h): error plumbing, timing ring,
 // weight packing, and the drivers that chain the kernels into forward_once /
 // DISTS.forward (nerf_qa/DISTS_pytorch/DISTS_pt.py:91-148).
+#include <math.h>
 #include <stdarg.h>
 #include <string.h>
 
@@ -102,6 +103,14 @@ static uint16_t f32_to_f16(float f) {
   if (rem > half || (rem == half && (r & 1u))) ++r;
   return (uint16_t)(sign | (base + r));
 }
+static float f16_to_f32(uint16_t hv) {
+  const int e = (hv >> 10) & 31, m = hv & 1023;
+  float v;
+  if (e == 0) v = ldexpf((float)m, -24);
+  else if (e == 31) v = m ? NAN : INFINITY;
+  else v = ldexpf((float)(m | 1024), e - 25);
+  return (hv & 0x8000) ? -v : v;
+}
 
 // ---- drivers ----------------------------------------------------------------------------
 struct PyrDims {
@@ -134,7 +143,7 @@ static int run_stages(const float *x, const float *y, int nx, void *bufA, void *
   const PyrDims d = pyr_dims(H, W);
   void *cur = bufA;
   int rc;
-  const bool fused1 = prec != NQA_PREC_F32;
+  const bool fused1 = prec_elem_bytes(prec) == 2;
   if (!fused1) {
     if ((rc = conv1_1(x, nx, H, W, packed, prec, bufA, st))) return rc;
     if (n > nx && (rc = conv1_1(y, n - nx, H, W, packed, prec,
@@ -168,7 +177,7 @@ static bool bad_dims(const char *who, int n, int H, int W, int prec) {
     set_error("%s: non-positive size n=%d H=%d W=%d", who, n, H, W);
     return true;
   }
-  if (prec != NQA_PREC_F32 && prec != NQA_PREC_BF16 && prec != NQA_PREC_F16) {
+  if (!prec_valid(prec)) {
     set_error("%s: unknown prec %d", who, prec);
     return true;
   }
@@ -264,7 +273,7 @@ int nqa_pack_vgg_weights(const float *const w_host[NQA_NUM_CONVS], const float *
     set_error("pack_vgg_weights: null pointer");
     return NQA_E_ARG;
   }
-  if (prec != NQA_PREC_F32 && prec != NQA_PREC_BF16 && prec != NQA_PREC_F16) {
+  if (!prec_valid(prec)) {
     set_error("pack_vgg_weights: unknown prec %d", prec);
     return NQA_E_ARG;
   }
@@ -276,7 +285,7 @@ int nqa_pack_vgg_weights(const float *const w_host[NQA_NUM_CONVS], const float *
       for (int c = 0; c < 3; ++c)
         for (int t = 0; t < 9; ++t) w0[(t * 3 + c) * 64 + co] = w_host[0][(co * 3 + c) * 9 + t];
     memcpy(blob + layer_bias_offset(0, prec), b_host[0], 64 * 4);
-    if (prec != NQA_PREC_F32) {  // MFMA A fragments for the fused stage-1 kernel
+    if (prec_elem_bytes(prec) == 2) {  // MFMA A fragments for the fused stage-1 kernel
       uint16_t *wm = reinterpret_cast<uint16_t *>(blob + layer0_mfma_offset(prec));
       for (int ky = 0; ky < 3; ++ky)
         for (int co = 0; co < 64; ++co)
@@ -288,11 +297,30 @@ int nqa_pack_vgg_weights(const float *const w_host[NQA_NUM_CONVS], const float *
             }
     }
   }
-  const int cpc = prec == NQA_PREC_F32 ? 4 : 8, kc = 4 * cpc;
+  const int cpc = prec_elem_bytes(prec) == 4 ? 4 : 8, kc = 4 * cpc;
   for (int l = 1; l < NQA_NUM_CONVS; ++l) {
     const ConvSpec &cs = kConvs[l];
     const int bn = 64, ncc = cs.cin / kc;
     char *dst = blob + layer_offset(l, prec);
+    if (prec == NQA_PREC_F32S) {
+      // rows of 16 input channels as [hi 0-7 | hi 8-15 | lo 0-7 | lo 8-15] halves, lo = f16(w - hi)
+      for (int ct = 0; ct < cs.cout / bn; ++ct)
+        for (int cc = 0; cc < ncc; ++cc)
+          for (int t = 0; t < 9; ++t)
+            for (int n = 0; n < bn; ++n)
+              for (int pos = 0; pos < 4; ++pos) {
+                const int c = pos ^ ((n >> 2) & 3);
+                uint16_t *row = reinterpret_cast<uint16_t *>(dst) + (((((size_t)ct * ncc + cc) * 9 + t) * bn + n) * 4 + pos) * 8;
+                for (int j = 0; j < 8; ++j) {
+                  const int cin = cc * 16 + (c & 1) * 8 + j, cout = ct * bn + n;
+                  const float v = w_host[l][((size_t)cout * cs.cin + cin) * 9 + t];
+                  const uint16_t hi = f32_to_f16(v);
+                  row[j] = c < 2 ? hi : f32_to_f16(v - f16_to_f32(hi));
+                }
+              }
+      memcpy(blob + layer_bias_offset(l, prec), b_host[l], (size_t)cs.cout * 4);
+      continue;
+    }
     for (int ct = 0; ct < cs.cout / bn; ++ct)
       for (int cc = 0; cc < ncc; ++cc)
         for (int t = 0; t < 9; ++t)

@@ -36,6 +36,7 @@ struct PrecF32 {
   static constexpr int ID = NQA_PREC_F32;
   static constexpr int CPC = 4;   // channels per 16-byte chunk
   static constexpr int KC = 16;   // channels per 64-byte LDS row
+  static constexpr bool SPLIT = false;
   __device__ static inline float to_f(T v) { return v; }
   __device__ static inline T from_f(float v) { return v; }
   // one chunk pair -> K=8 of the contraction as four exact-f32 MFMAs (K=2 each)
@@ -48,11 +49,19 @@ struct PrecF32 {
     return c;
   }
 };
+// float storage like PrecF32, but the convolutions run on the f16 MFMA with both operands split
+// into f16 (hi, lo) pairs: a*b ~= ah*bh + ah*bl + al*bh (the dropped al*bl is ~2^-22 relative).
+// Weights are pre-split at pack time; activations are split in registers after the LDS read.
+struct PrecF32S : PrecF32 {
+  static constexpr int ID = NQA_PREC_F32S;
+  static constexpr bool SPLIT = true;
+};
 struct PrecBF16 {
   typedef __bf16 T;
   static constexpr int ID = NQA_PREC_BF16;
   static constexpr int CPC = 8;
   static constexpr int KC = 32;
+  static constexpr bool SPLIT = false;
   __device__ static inline float to_f(T v) { return (float)v; }
   __device__ static inline T from_f(float v) { return (T)v; }
   __device__ static inline f32x16 mma(u32x4 a, u32x4 b, f32x16 c) {
@@ -65,6 +74,7 @@ struct PrecF16 {
   static constexpr int ID = NQA_PREC_F16;
   static constexpr int CPC = 8;
   static constexpr int KC = 32;
+  static constexpr bool SPLIT = false;
   __device__ static inline float to_f(T v) { return (float)v; }
   __device__ static inline T from_f(float v) { return (T)v; }
   __device__ static inline f32x16 mma(u32x4 a, u32x4 b, f32x16 c) {
@@ -73,7 +83,12 @@ struct PrecF16 {
   }
 };
 
-__host__ __device__ static inline size_t prec_elem_bytes(int prec) { return prec == NQA_PREC_F32 ? 4 : 2; }
+__host__ __device__ static inline size_t prec_elem_bytes(int prec) {
+  return prec == NQA_PREC_F32 || prec == NQA_PREC_F32S ? 4 : 2;
+}
+static inline bool prec_valid(int prec) { return prec >= NQA_PREC_F32 && prec <= NQA_PREC_F32S; }
+// the precision every non-conv kernel sees: f32s activations are plain float
+static inline int storage_prec(int prec) { return prec == NQA_PREC_F32S ? NQA_PREC_F32 : prec; }
 
 // ---- VGG plan --------------------------------------------------------------------
 struct ConvSpec {

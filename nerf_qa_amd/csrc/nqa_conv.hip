@@ -309,6 +309,58 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void conv3x3_igemm_kernel(
       for (int j = 0; j < WM_T; ++j) asm volatile("" ::"v"(bf[j]));
 #endif
     };
+    if constexpr (P::SPLIT) {
+      // split-f16 products: a 64-byte weight row is [hi 0-7 | hi 8-15 | lo 0-7 | lo 8-15] halves of
+      // 16 input channels, a pixel row is the same 16 channels as floats.  One k-step per tap:
+      // lane half h contracts channels 8h..8h+7 (weight chunks h and 2+h, pixel chunks 2h, 2h+1).
+      auto load_split = [&](int kx, u32x4(&ah)[WN_T], u32x4(&al)[WN_T], u32x4(&pr)[WM_T][2]) {
+#pragma unroll
+        for (int i = 0; i < WN_T; ++i) {
+          const char *row = wbuf + w_base[i] + kx * 4096;
+          ah[i] = *reinterpret_cast<const u32x4 *>(row + ((h ^ w_sw[i]) << 4));
+          al[i] = *reinterpret_cast<const u32x4 *>(row + (((2 + h) ^ w_sw[i]) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < WM_T; ++j) {
+          const int q = q0[j] + ky * G::HW_ + kx, sw = (q >> 2) & 3;
+          pr[j][0] = *reinterpret_cast<const u32x4 *>(abuf + q * 64 + (((2 * h) ^ sw) << 4));
+          pr[j][1] = *reinterpret_cast<const u32x4 *>(abuf + q * 64 + (((2 * h + 1) ^ sw) << 4));
+        }
+      };
+      auto mma_split = [&](const u32x4(&ah)[WN_T], const u32x4(&al)[WN_T], const u32x4(&pr)[WM_T][2]) {
+        f16x8 bh[WM_T], bl[WM_T];
+#pragma unroll
+        for (int j = 0; j < WM_T; ++j)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float v = __builtin_bit_cast(f32x4, pr[j][e >> 2])[e & 3];
+            const _Float16 hi = (_Float16)v;
+            bh[j][e] = hi;
+            bl[j][e] = (_Float16)(v - (float)hi);
+          }
+        // term by term, so consecutive MFMAs never hit the same accumulator
+#pragma unroll
+        for (int term = 0; term < 3; ++term)
+#pragma unroll
+          for (int i = 0; i < WN_T; ++i)
+#pragma unroll
+            for (int j = 0; j < WM_T; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, term == 0 ? al[i] : ah[i]),
+                                                                 term == 1 ? bl[j] : bh[j], acc[i][j], 0, 0, 0);
+      };
+      u32x4 ahA[WN_T], alA[WN_T], prA[WM_T][2], ahB[WN_T], alB[WN_T], prB[WM_T][2];
+      load_split(0, ahA, alA, prA);
+      load_split(1, ahB, alB, prB);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_split(ahA, alA, prA);
+      __builtin_amdgcn_sched_barrier(0);
+      load_split(2, ahA, alA, prA);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_split(ahB, alB, prB);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_split(ahA, alA, prA);
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
     // sched_barrier(0) pins "reads of the next step, then MFMAs of this step": left alone,
     // hipcc sinks every ds_read to just before its MFMA and waits lgkmcnt(0) each time
     u32x4 afA[WN_T], bfA[WM_T], afB[WN_T], bfB[WM_T];
@@ -323,6 +375,7 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void conv3x3_igemm_kernel(
       __builtin_amdgcn_sched_barrier(0);
       mma_all(afB, bfB);
       __builtin_amdgcn_sched_barrier(0);
+    }
     }
     NQA_STAMP(t4);
     NQA_STAMP_ADD(3, t3, t4);
@@ -725,8 +778,10 @@ static int launch_conv(const void *in, int n, int H, int W, int layer, const cha
   return narrow ? launch_igemm<P, WN, WM, TN, TM, 16>(in, n, H, W, cs.cin, cs.cout, wpk, bias, out, st) \
                 : launch_igemm<P, WN, WM, TN, TM, 32>(in, n, H, W, cs.cin, cs.cout, wpk, bias, out, st)
   if (cs.cout == 64) { NQA_GO(1, 4, 2, 2); }                    // 64 ch x 256 px, 4 waves
-  if (!big) { NQA_GO(2, 2, 2, 2); }                             // 128 ch x 128 px, 4 waves
-  NQA_GO(2, 4, 4, 2);                                           // 256 ch x 256 px, 8 waves
+  if (!big || P::SPLIT) { NQA_GO(2, 2, 2, 2); }                 // 128 ch x 128 px, 4 waves
+  if constexpr (!P::SPLIT) {  // (split mode keeps two fragment sets of 3 operands: 4-wave tiles only)
+    NQA_GO(2, 4, 4, 2);                                         // 256 ch x 256 px, 8 waves
+  }
 #undef NQA_GO
 }
 
@@ -779,6 +834,7 @@ int conv1_fused(const float *x, const float *y, int B, int n, int H, int W, cons
 }
 
 int conv1_1(const float *x, int n, int H, int W, const void *packed, int prec, void *out, hipStream_t st) {
+  prec = storage_prec(prec);
   const char *p = static_cast<const char *>(packed);
   switch (prec) {
     case NQA_PREC_F32: return launch_conv1_1<PrecF32>(x, n, H, W, p, out, st);
@@ -795,6 +851,7 @@ int conv3x3(const void *in, int n, int H, int W, int layer, const void *packed, 
     case NQA_PREC_F32: return launch_conv<PrecF32>(in, n, H, W, layer, p, out, st);
     case NQA_PREC_BF16: return launch_conv<PrecBF16>(in, n, H, W, layer, p, out, st);
     case NQA_PREC_F16: return launch_conv<PrecF16>(in, n, H, W, layer, p, out, st);
+    case NQA_PREC_F32S: return launch_conv<PrecF32S>(in, n, H, W, layer, p, out, st);
   }
   set_error("conv3x3: unknown prec %d", prec);
   return NQA_E_ARG;

@@ -369,6 +369,7 @@ static int launch_l2pool(const void *in, int n, int H, int W, int C, void *out, 
 }
 
 int l2pool(const void *in, int n, int H, int W, int C, int prec, void *out, hipStream_t st) {
+  prec = storage_prec(prec);
   switch (prec) {
     case NQA_PREC_F32: return launch_l2pool<PrecF32>(in, n, H, W, C, out, st);
     case NQA_PREC_BF16: return launch_l2pool<PrecBF16>(in, n, H, W, C, out, st);
@@ -384,6 +385,7 @@ int l2pool(const void *in, int n, int H, int W, int C, int prec, void *out, hipS
 // strips would cost more in partials than they read), sized for ~1024 blocks over the batch,
 // and never more than ~4096 so the finalize pass stays short.
 int stats_units_per_block(int units, int C, int prec, int B) {
+  prec = storage_prec(prec);
   const int cpc = prec == NQA_PREC_F32 ? 4 : 8;
   const int PL = 256 / (C / cpc);
   if (B < 1) B = 1;
@@ -406,6 +408,7 @@ static int launch_stats_nhwc(const void *feat, int B, int HW, int C, double *par
 }
 
 int stats_nhwc(const void *feat, int B, int HW, int C, int prec, double *part, hipStream_t st) {
+  prec = storage_prec(prec);
   switch (prec) {
     case NQA_PREC_F32: return launch_stats_nhwc<PrecF32>(feat, B, HW, C, part, st);
     case NQA_PREC_BF16: return launch_stats_nhwc<PrecBF16>(feat, B, HW, C, part, st);
@@ -418,6 +421,7 @@ int stats_nhwc(const void *feat, int B, int HW, int C, int prec, double *part, h
 // Tile shape of the fused pool+statistics pass for an Ho x Wo pooled map: up to 8 rows tall,
 // units_per_block pixels in all; returns the number of tiles (= blocks per image pair).
 int pool_stats_tiles(int Ho, int Wo, int C, int prec, int B, int *tr, int *tc) {
+  prec = storage_prec(prec);
   const int upb = stats_units_per_block(Ho * Wo, C, prec, B);
   int TR = 8;
   while (TR > 1 && (upb % TR || upb / TR < 4 || TR > Ho)) TR >>= 1;
@@ -443,6 +447,7 @@ static int launch_pool_stats(const void *feat, int B, int H, int W, int C, void 
 
 // tap (2B images: x then y) -> pooled (2B images) + statistics partials of the B pairs
 int pool_stats(const void *feat, int B, int H, int W, int C, int prec, void *pooled, double *part, hipStream_t st) {
+  prec = storage_prec(prec);
   switch (prec) {
     case NQA_PREC_F32: return launch_pool_stats<PrecF32>(feat, B, H, W, C, pooled, part, st);
     case NQA_PREC_BF16: return launch_pool_stats<PrecBF16>(feat, B, H, W, C, pooled, part, st);
@@ -481,6 +486,7 @@ static int launch_export(const void *in, int n, int HW, int C, float *out, hipSt
 }
 
 int nhwc_to_nchw(const void *in, int n, int HW, int C, int prec, float *out, hipStream_t st) {
+  prec = storage_prec(prec);
   switch (prec) {
     case NQA_PREC_F32: return launch_export<PrecF32>(in, n, HW, C, out, st);
     case NQA_PREC_BF16: return launch_export<PrecBF16>(in, n, HW, C, out, st);

@@ -94,6 +94,36 @@ def test_pack_roundtrip(prec, np_convs, lib):
         assert np.array_equal(bias, np_convs[l][1])
 
 
+def test_pack_split_f16(np_convs, lib):
+    """f32s blob: every weight as an f16 (hi, lo) pair, hi + lo == w to ~2^-21, rows [hi0-7|hi8-15|lo0-7|lo8-15]."""
+    from nerf_qa_amd import ops
+    blob = ops.pack_vgg_weights(np_convs, "f32s").numpy()
+    assert blob.nbytes == ops.pack_vgg_weights(np_convs, "f32").numpy().nbytes
+    al = lambda v: (v + 255) // 256 * 256
+    off = 256 + al(27 * 64 * 4 + 64 * 4) + 6144
+    for l in (1, 4, 12):
+        cin, cout = ops.CONV_CIN[l], ops.CONV_COUT[l]
+        o = off + sum(al(ops.CONV_CIN[i] * ops.CONV_COUT[i] * 9 * 4) + al(ops.CONV_COUT[i] * 4) for i in range(1, l))
+        ncc = cin // 16
+        t = blob[o:o + cin * cout * 36].view(np.float16).reshape(cout // 64, ncc, 9, 64, 4, 8)
+        w = np_convs[l][0].reshape(cout, cin, 9)
+        hi = np.zeros((cout, cin, 9), np.float16)
+        lo = np.zeros((cout, cin, 9), np.float16)
+        for n in range(64):
+            for pos in range(4):
+                c = pos ^ ((n >> 2) & 3)
+                dst = hi if c < 2 else lo
+                for cc in range(ncc):
+                    ch = cc * 16 + (c & 1) * 8
+                    dst[n::64, ch:ch + 8, :] = t[:, cc, :, n, pos, :].transpose(0, 2, 1)
+        assert np.array_equal(hi, w.astype(np.float16))
+        assert np.array_equal(lo, (w - hi.astype(np.float32)).astype(np.float16))
+        rec = hi.astype(np.float64) + lo.astype(np.float64)
+        assert np.abs(rec - w).max() <= 2.0 ** -21 * np.abs(w).max()
+        bias = blob[o + al(cin * cout * 36):][:cout * 4].view(np.float32)
+        assert np.array_equal(bias, np_convs[l][1])
+
+
 def test_no_cpu_fallback():
     """CPU tensors must be refused, not silently computed somewhere else."""
     from nerf_qa_amd import _lib, ops

@@ -26,8 +26,9 @@ def models(dev):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         m = {"f16": DISTS(precision="f16").to(dev).eval(), "f32": DISTS(precision="f32").to(dev).eval(),
-             "a16": ADISTS(precision="f16").to(dev).eval(), "a32": ADISTS(precision="f32").to(dev).eval()}
-        assert DISTS().precision == "f16" and ADISTS().precision == "f32"  # the shipped defaults
+             "a16": ADISTS(precision="f16").to(dev).eval(), "a32": ADISTS(precision="f32").to(dev).eval(),
+             "a32s": ADISTS(precision="f32s").to(dev).eval(), "f32s": DISTS(precision="f32s").to(dev).eval()}
+        assert DISTS().precision == "f16" and ADISTS().precision == "f32s"  # the shipped defaults
         return m
 
 
@@ -55,6 +56,9 @@ def test_dists_full_size_properties(b, h, w, models, dev):
         d = (s16 - s32).abs().max().item()
         print(f"\nDISTS {b}x{h}x{w}: score range [{s32.min().item():.4f}, {s32.max().item():.4f}] |f16-f32|={d:.2e}")
         assert d <= 1e-4
+        ds = (models["f32s"](x, y) - s32).abs().max().item()
+        print(f"   |f32s-f32|={ds:.2e}")
+        assert ds <= 5e-6
         # identical inputs -> 0
         assert models["f16"](x[:2], x[:2].clone()).abs().max().item() < 2e-6
         # symmetry
@@ -77,7 +81,11 @@ def test_adists_full_size_properties(b, h, w, models, dev):
         # the opt-in f16 mode: A-DISTS' min-max / sigmoid chain amplifies 16-bit feature rounding on some
         # (blurred) inputs to a few 1e-4 -- the reason its default is f32; held to 1e-3 here
         assert torch.isfinite(a16).all() and d <= 1e-3
-        for key in ("a32", "a16"):
+        # the split-f16 mode (f32 storage, 3 half MFMAs per product) must track exact f32
+        ds = (models["a32s"](x, y, as_loss=False) - a32).abs().max().item()
+        print(f"   |f32s-f32|={ds:.2e}")
+        assert ds <= 2e-5
+        for key in ("a32", "a16", "a32s"):
             full = models[key](x, y, as_loss=False)
             assert models[key](x[:1], x[:1].clone(), as_loss=False).abs().max().item() < 1e-5
             alone = models[key](x[1:2], y[1:2], as_loss=False)
@@ -96,9 +104,9 @@ def test_small_and_ragged_sizes_vs_oracle(h, w, models, oracle_convs, dev):
     ref = dists_oracle.dists(x, y, oracle_convs, m.alpha.detach().cpu(), m.beta.detach().cpu())
     aref = adists_oracle.adists(x, y, oracle_convs)
     with torch.no_grad():
-        for key, tol in (("f32", 5e-6), ("f16", 1e-4)):
+        for key, tol in (("f32", 5e-6), ("f32s", 5e-6), ("f16", 1e-4)):
             got = models[key](x.to(dev), y.to(dev)).cpu()
             assert (got - ref).abs().max().item() <= tol, (key, got, ref)
-        for key, tol in (("a32", 2e-5), ("a16", 1e-3)):
+        for key, tol in (("a32", 2e-5), ("a32s", 2e-5), ("a16", 1e-3)):
             got = models[key](x.to(dev), y.to(dev), as_loss=False).cpu()
             assert (got - aref).abs().max().item() <= tol, (key, got, aref)

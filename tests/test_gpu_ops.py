@@ -2,6 +2,7 @@
 
 Every call goes through the C ABI (nerf_qa_amd.ops -> libnqa_hip.so).  Tolerances:
   f32  : accumulation-order differences only            -> 2e-5 relative to the map's scale
+  f32s : split-f16 products (hi*hi + hi*lo + lo*hi), ~2^-21 per product -> same bar as f32
   f16  : + one rounding of each stored activation (2^-11)
   bf16 : + one rounding of each stored activation (2^-8)
 """
@@ -12,9 +13,9 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-PRECS = ["f32", "f16", "bf16"]
-DT = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}
-OUT_RTOL = {"f32": 2e-5, "f16": 1.2e-3, "bf16": 9e-3}
+PRECS = ["f32", "f32s", "f16", "bf16"]
+DT = {"f32": torch.float32, "f32s": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}
+OUT_RTOL = {"f32": 2e-5, "f32s": 2e-5, "f16": 1.2e-3, "bf16": 9e-3}
 
 
 @pytest.fixture(scope="module")

@@ -13,7 +13,9 @@ from nerf_qa_amd import ops, synth  # noqa: E402
 dev = torch.device("cuda:0")
 which = sys.argv[1] if len(sys.argv) > 1 else "256"
 H, W, N = (256, 256, 64) if which == "256" else (1080, 1920, 8)
-prec = "f16"
+import os
+prec = os.environ.get("NQA_TOOL_PREC", "f16")
+DT = {"f16": torch.float16, "bf16": torch.bfloat16}.get(prec, torch.float32)
 packed = ops.pack_vgg_weights(synth.vgg16_weights(1234), prec).to(dev)
 dims = ops.pyramid_dims(H, W)
 VARIANTS = (0, 1)
@@ -30,14 +32,14 @@ def time_layer(a, layer, reps):
 
 
 # warm-up: ~0.5 s of conv work so clocks settle
-a = (torch.rand(N, dims[2][0], dims[2][1], 256, device=dev) - 0.5).clamp_min(0).half()
+a = (torch.rand(N, dims[2][0], dims[2][1], 256, device=dev) - 0.5).clamp_min(0).to(DT)
 time_layer(a, 5, 300 if which == "256" else 40)
 res = {v: [] for v in VARIANTS}
 tot = {v: [0.0, 0.0] for v in VARIANTS}
 for layer in range(1, 13):
     h, w = dims[ops.CONV_STAGE[layer]]
     cin, cout = ops.CONV_CIN[layer], ops.CONV_COUT[layer]
-    a = (torch.rand(N, h, w, cin, device=dev) - 0.5).clamp_min(0).half()
+    a = (torch.rand(N, h, w, cin, device=dev) - 0.5).clamp_min(0).to(DT)
     fl = 2 * 9 * cin * cout * h * w * N
     best = {v: 1e9 for v in VARIANTS}
     for rnd in range(3):

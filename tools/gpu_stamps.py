@@ -4,8 +4,10 @@ import sys
 import torch
 sys.path.insert(0, __file__.rsplit("/", 2)[0])
 from nerf_qa_amd import ops, synth, _lib  # noqa: E402
+import os
 dev = torch.device("cuda:0")
-packed = ops.pack_vgg_weights(synth.vgg16_weights(1234), "f16").to(dev)
+PREC = os.environ.get("NQA_TOOL_PREC", "f16")
+packed = ops.pack_vgg_weights(synth.vgg16_weights(1234), PREC).to(dev)
 L = _lib.lib()
 fn = C.CDLL(_lib.LIB_PATH).nqa_debug_stamps
 buf = (C.c_ulonglong * 8)()
@@ -13,12 +15,12 @@ dims = ops.pyramid_dims(256, 256)
 for layer, variant in ((8, 1), (8, 0), (5, 1), (3, 0), (1, 0)):
     ops.set_conv_variant(variant)
     h, w = dims[ops.CONV_STAGE[layer]]
-    a = (torch.rand(64, h, w, ops.CONV_CIN[layer], device=dev) - 0.5).clamp_min(0).half()
+    a = (torch.rand(64, h, w, ops.CONV_CIN[layer], device=dev) - 0.5).clamp_min(0).to(_lib.PREC_DTYPE[_lib.prec_id(PREC)])
     for _ in range(3):
-        ops.conv3x3_relu(a, layer, packed, "f16")
+        ops.conv3x3_relu(a, layer, packed, PREC)
     torch.cuda.synchronize()
     fn(buf, 1)
-    ops.conv3x3_relu(a, layer, packed, "f16")
+    ops.conv3x3_relu(a, layer, packed, PREC)
     torch.cuda.synchronize()
     fn(buf, 1)
     nst = buf[4]
