@@ -142,6 +142,33 @@ size_t nqa_adists_workspace_bytes(int B, int H, int W, int prec);
 int nqa_adists_forward(const float *x_nchw, const float *y_nchw, int B, int H, int W, const void *packed_w, int prec,
                        void *workspace, size_t workspace_bytes, float *d, void *stream);
 
+/* The same pass with as_map=True (ADISTS.py:163,188-189,193): additionally map[b] (dev float32
+ * (B,H,W)) = 1 - sum over stages of the stage's distortion map resized bilinearly
+ * (align_corners=False) to H x W.  The reference's return value broadcasts this to (B,B,H,W)
+ * with out[i][j] = map[i] for every j (its (B,H,W) + (B,1,H,W) addition); the Python shell
+ * reproduces that shape. */
+int nqa_adists_forward_map(const float *x_nchw, const float *y_nchw, int B, int H, int W, const void *packed_w,
+                           int prec, void *workspace, size_t workspace_bytes, float *d, float *map, void *stream);
+
+/* ---- input preparation on the device (decoded uint8 frame -> metric input) ------------ */
+
+/* transforms.ToTensor / `torch.from_numpy(frame).permute(2,0,1).float() / 255.0` (prep.py:89,
+ * data.py:80): in dev uint8 (n,H,W,3) -> out dev float32 (n,3,H,W).  pil_roundtrip != 0 also
+ * applies prep.py:90-91's ToPILImage -> ToTensor round trip (mul(255).byte() truncates). */
+int nqa_u8hwc_to_f32nchw(const uint8_t *in, int n, int H, int W, int pil_roundtrip, float *out, void *stream);
+
+/* F.interpolate(x, size=(Hout,Wout), mode='bilinear', align_corners=False) (prep.py:93-95,
+ * data.py:81-82, test2_prep.py:437) on `planes` = n*C float32 planes of Hin x Win. */
+int nqa_resize_bilinear_f32(const float *in, int planes, int Hin, int Win, int Hout, int Wout, float *out,
+                            void *stream);
+
+/* transforms.functional.resize on a PIL image (DISTS_pt.py:213-215, test2_prep.py:112,225) =
+ * PIL Image.resize((Wout,Hout), BILINEAR): Pillow's antialiased two-pass 8-bit resampler,
+ * bit-exact.  in dev uint8 (n,Hin,Win,3) -> out dev uint8 (n,Hout,Wout,3). */
+size_t nqa_resize_pil_workspace_bytes(int n, int Hin, int Win, int Hout, int Wout);
+int nqa_resize_pil_bilinear_u8(const uint8_t *in, int n, int Hin, int Win, int Hout, int Wout, void *workspace,
+                               size_t workspace_bytes, uint8_t *out, void *stream);
+
 /* ---- tuning hook ------------------------------------------------------------------ */
 
 /* Block-tile choice of the implicit-GEMM conv: 0 = 4-wave tiles (128 ch x 128 px) on every
@@ -155,7 +182,7 @@ int nqa_set_conv_variant(int variant);
  * pair of hipEvents recorded on the launch stream.  nqa_timing_collect synchronises
  * those events and returns, per kernel class, the number of launches and the summed
  * device time in milliseconds, then clears the ring. */
-enum { NQA_K_CONV1 = 0, NQA_K_CONV = 1, NQA_K_POOL = 2, NQA_K_STATS = 3, NQA_K_ADISTS = 4, NQA_K_COUNT = 5 };
+enum { NQA_K_CONV1 = 0, NQA_K_CONV = 1, NQA_K_POOL = 2, NQA_K_STATS = 3, NQA_K_ADISTS = 4, NQA_K_PREP = 5, NQA_K_COUNT = 6 };
 int nqa_timing_enable(int on);
 int nqa_timing_collect(int launches[NQA_K_COUNT], double ms[NQA_K_COUNT]);
 

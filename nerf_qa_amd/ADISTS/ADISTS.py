@@ -16,8 +16,8 @@ in the score, which breaks the 1e-4 bar DISTS' smooth statistics keep with margi
 precision="f16" stays available as the opt-in fast mode (3x the throughput at 1080p).
 
 as_loss=True in the reference runs the pyramids WITH autograd (:139-141); this build has
-no VGG backward, so the value 1-mean(D) is returned without a graph.  as_map=True (the
-[B,B,H,W] distortion map, :188-193) is outside the hot path and raises.
+no VGG backward, so the value 1-mean(D) is returned without a graph.  as_map=True returns the
+reference's [B,B,H,W] distortion map (:163,188-193) from one extra kernel.
 """
 from __future__ import annotations
 
@@ -94,7 +94,11 @@ class ADISTS(torch.nn.Module):
     def forward(self, x, y, as_loss=True, as_map=False):
         assert x.shape == y.shape
         if as_map:
-            raise NotImplementedError("as_map=True (the full-resolution distortion map) is not part of this build")
+            # (:163,188-189,193) the reference's (B,H,W) + (B,1,H,W) addition broadcasts to (B,B,H,W)
+            # with out[i, j] = map[i]; reproduced as is (callers use B = 1, nerf_nr_qa_prep_4.py:70)
+            _, m = ops.adists_forward(x, y, self._packed_weights(x.device), self.precision, self._ws, with_map=True)
+            b = m.shape[0]
+            return m.unsqueeze(1).expand(b, b, *m.shape[1:]).contiguous()
         d = ops.adists_forward(x, y, self._packed_weights(x.device), self.precision, self._ws)
         if as_loss:
             return 1 - d.mean()

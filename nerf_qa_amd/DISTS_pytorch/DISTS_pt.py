@@ -189,5 +189,5 @@ def prepare_image(image, resize=True, keep_aspect_ratio=False):
             image = image.resize((nw, nh), Image.BILINEAR)
         else:
             image = image.resize((256, 256), Image.BILINEAR)
-    arr = np.asarray(image.convert("RGB"), dtype=np.uint8)
+    arr = np.array(image.convert("RGB"), dtype=np.uint8)
     return torch.from_numpy(arr).permute(2, 0, 1).float().div(255).unsqueeze(0)

@@ -18,7 +18,7 @@ PREC_NAMES = {"f32": PREC_F32, "fp32": PREC_F32, "bf16": PREC_BF16, "f16": PREC_
               "f32s": PREC_F32S}
 PREC_DTYPE = {PREC_F32: torch.float32, PREC_BF16: torch.bfloat16, PREC_F16: torch.float16, PREC_F32S: torch.float32}
 NUM_CONVS, NUM_TAPS, TOTAL_CHNS = 13, 6, 1475
-K_NAMES = ("conv1_1", "conv_igemm", "l2pool", "stats", "adists")
+K_NAMES = ("conv1_1", "conv_igemm", "l2pool", "stats", "adists", "prep")
 
 _vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
 _SIGNATURES = {
@@ -40,6 +40,11 @@ _SIGNATURES = {
     "nqa_dists_score": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "nqa_adists_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "nqa_adists_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _sz, _vp, _vp]),
+    "nqa_adists_forward_map": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _sz, _vp, _vp, _vp]),
+    "nqa_u8hwc_to_f32nchw": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "nqa_resize_bilinear_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "nqa_resize_pil_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "nqa_resize_pil_bilinear_u8": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp]),
     "nqa_set_conv_variant": (_i, [_i]),
     "nqa_timing_enable": (_i, [_i]),
     "nqa_timing_collect": (_i, [C.POINTER(_i), C.POINTER(C.c_double)]),

@@ -629,6 +629,47 @@ __global__ void adists_d_kernel(const ChainAcc *acc, DDesc d, int B, float *out)
   out[b] = s;
 }
 
+// as_map=True (ADISTS.py:163,188-189,193): 1 - sum over stages (coarse to fine, the reference's loop
+// order) of the stage's D map bilinearly resized to (H, W), align_corners=False.  The stage map is
+// rebuilt from the chain's ps_prod and the window pass' TW / SW maps.
+struct MapDesc {
+  const float *ps[NQA_NUM_TAPS], *tw[NQA_NUM_TAPS], *sw[NQA_NUM_TAPS];
+  int mh[NQA_NUM_TAPS], mw[NQA_NUM_TAPS];
+};
+__device__ inline void src_index(int dst, int in, int out, int &i0, int &i1, float &l0, float &l1) {
+  // torch upsample_bilinear2d, align_corners=False: src = in/out * (dst + 0.5) - 0.5, clamped at 0
+  const float scale = (float)in / (float)out;
+  float src = scale * ((float)dst + 0.5f) - 0.5f;
+  src = src < 0.f ? 0.f : src;
+  i0 = (int)src;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+  l0 = 1.f - l1;
+}
+__global__ __launch_bounds__(256) void adists_map_kernel(MapDesc d, int H, int W, float *__restrict__ out) {
+  const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= H * W) return;
+  const int y = i / W, x = i - y * W;
+  float s = 0.f;
+  for (int k = NQA_NUM_TAPS - 1; k >= 0; --k) {
+    const int mh = d.mh[k], mw = d.mw[k];
+    const size_t o = (size_t)b * mh * mw;
+    const float *ps = d.ps[k] + o, *tw = d.tw[k] + o, *sw = d.sw[k] + o;
+    auto dm = [&](int yy, int xx) {
+      const int j = yy * mw + xx;
+      const float p = ps[j];
+      return (1.f - p) * tw[j] + p * sw[j];
+    };
+    int y0, y1, x0, x1;
+    float ly0, ly1, lx0, lx1;
+    src_index(y, mh, H, y0, y1, ly0, ly1);
+    src_index(x, mw, W, x0, x1, lx0, lx1);
+    s = s + (ly0 * (lx0 * dm(y0, x0) + lx1 * dm(y0, x1)) + ly1 * (lx0 * dm(y1, x0) + lx1 * dm(y1, x1)));
+  }
+  out[(size_t)b * H * W + i] = 1.f - s;
+}
+
 // ---------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------
@@ -797,8 +838,10 @@ size_t nqa_adists_workspace_bytes(int B, int H, int W, int prec) {
   return make_plan(B, H, W, prec).total;
 }
 
-int nqa_adists_forward(const float *x, const float *y, int B, int H, int W, const void *packed, int prec, void *ws,
-                       size_t ws_bytes, float *d_out, void *stream) {
+}  // extern "C"
+
+static int adists_run(const float *x, const float *y, int B, int H, int W, const void *packed, int prec, void *ws,
+                      size_t ws_bytes, float *d_out, float *map_out, void *stream) {
   if (!x || !y || !packed || !ws || !d_out) {
     set_error("adists_forward: null pointer");
     return NQA_E_ARG;
@@ -969,7 +1012,36 @@ int nqa_adists_forward(const float *x, const float *y, int B, int H, int W, cons
     adists_d_kernel<<<cdiv(B, 256), 256, 0, st>>>(acc, dd, B, d_out);
     if ((rc = check_launch("adists_chain"))) return rc;
   }
+  if (map_out) {
+    MapDesc md;
+    for (int k = 0; k < 6; ++k) {
+      md.tw[k] = reinterpret_cast<const float *>(base + p.maps[k][1]);
+      md.sw[k] = reinterpret_cast<const float *>(base + p.maps[k][2]);
+      md.ps[k] = reinterpret_cast<const float *>(base + p.maps[k][3]);
+      md.mh[k] = p.mh[k];
+      md.mw[k] = p.mw[k];
+    }
+    TimedLaunch t(NQA_K_ADISTS, st);
+    adists_map_kernel<<<dim3(cdiv(H * W, 256), B), 256, 0, st>>>(md, H, W, map_out);
+    if ((rc = check_launch("adists_map"))) return rc;
+  }
   return NQA_OK;
+}
+
+extern "C" {
+
+int nqa_adists_forward(const float *x, const float *y, int B, int H, int W, const void *packed, int prec, void *ws,
+                       size_t ws_bytes, float *d_out, void *stream) {
+  return adists_run(x, y, B, H, W, packed, prec, ws, ws_bytes, d_out, nullptr, stream);
+}
+
+int nqa_adists_forward_map(const float *x, const float *y, int B, int H, int W, const void *packed, int prec,
+                           void *ws, size_t ws_bytes, float *d_out, float *map_out, void *stream) {
+  if (!map_out) {
+    set_error("adists_forward_map: null map pointer");
+    return NQA_E_ARG;
+  }
+  return adists_run(x, y, B, H, W, packed, prec, ws, ws_bytes, d_out, map_out, stream);
 }
 
 }  // extern "C"

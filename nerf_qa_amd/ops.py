@@ -213,14 +213,17 @@ def timing_enable(on: bool) -> None:
 
 
 def timing_collect():
-    n = (C.c_int * 5)()
-    ms = (C.c_double * 5)()
+    n = (C.c_int * len(_lib.K_NAMES))()
+    ms = (C.c_double * len(_lib.K_NAMES))()
     check(lib().nqa_timing_collect(n, ms))
     return {name: (n[i], ms[i]) for i, name in enumerate(_lib.K_NAMES)}
 
 
-def adists_forward(x: torch.Tensor, y: torch.Tensor, packed: torch.Tensor, prec, ws: Workspace | None = None):
-    """D (B,) float32 of ADISTS.forward (ADISTS.py:147-191); the caller returns 1-D or 1-mean(D)."""
+def adists_forward(x: torch.Tensor, y: torch.Tensor, packed: torch.Tensor, prec, ws: Workspace | None = None,
+                   with_map: bool = False):
+    """D (B,) float32 of ADISTS.forward (ADISTS.py:147-191); the caller returns 1-D or 1-mean(D).
+
+    with_map=True also returns the as_map=True distortion map (ADISTS.py:188-189,193) as (B,H,W)."""
     p = prec_id(prec)
     dev = _need_cuda(x, y, packed)
     x, y = _f32c(x), _f32c(y)
@@ -230,6 +233,53 @@ def adists_forward(x: torch.Tensor, y: torch.Tensor, packed: torch.Tensor, prec,
     d = torch.empty((b,), dtype=torch.float32, device=dev)
     nbytes = lib().nqa_adists_workspace_bytes(b, h, w, p)
     buf = (ws or Workspace()).get(nbytes, dev)
+    if with_map:
+        m = torch.empty((b, h, w), dtype=torch.float32, device=dev)
+        check(lib().nqa_adists_forward_map(ptr(x), ptr(y), b, h, w, ptr(packed), p, ptr(buf), buf.numel(), ptr(d),
+                                           ptr(m), stream_ptr(dev)))
+        return d, m
     check(lib().nqa_adists_forward(ptr(x), ptr(y), b, h, w, ptr(packed), p, ptr(buf), buf.numel(), ptr(d),
                                    stream_ptr(dev)))
     return d
+
+
+# ---- input preparation ---------------------------------------------------
+def u8hwc_to_f32nchw(frames: torch.Tensor, pil_roundtrip: bool = False) -> torch.Tensor:
+    """ToTensor on the device: uint8 (n,H,W,3) -> float32 (n,3,H,W) / 255 (prep.py:89, data.py:80)."""
+    dev = _need_cuda(frames)
+    if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[3] != 3:
+        raise ValueError(f"expected uint8 (n,H,W,3), got {frames.dtype} {tuple(frames.shape)}")
+    frames = frames.contiguous()
+    n, h, w, _ = frames.shape
+    out = torch.empty((n, 3, h, w), dtype=torch.float32, device=dev)
+    check(lib().nqa_u8hwc_to_f32nchw(ptr(frames), n, h, w, int(pil_roundtrip), ptr(out), stream_ptr(dev)))
+    return out
+
+
+def resize_bilinear_f32(x: torch.Tensor, size) -> torch.Tensor:
+    """F.interpolate(x, size=size, mode='bilinear', align_corners=False) for float32 (n,C,H,W)."""
+    dev = _need_cuda(x)
+    x = _f32c(x)
+    if x.dim() != 4:
+        raise ValueError(f"expected (n,C,H,W), got {tuple(x.shape)}")
+    ho, wo = (int(size), int(size)) if isinstance(size, int) else (int(size[0]), int(size[1]))
+    n, c, h, w = x.shape
+    out = torch.empty((n, c, ho, wo), dtype=torch.float32, device=dev)
+    check(lib().nqa_resize_bilinear_f32(ptr(x), n * c, h, w, ho, wo, ptr(out), stream_ptr(dev)))
+    return out
+
+
+def resize_pil_bilinear_u8(frames: torch.Tensor, size, ws: Workspace | None = None) -> torch.Tensor:
+    """PIL Image.resize((W,H), BILINEAR) on uint8 (n,H,W,3) frames, bit-exact; size = (Hout, Wout)."""
+    dev = _need_cuda(frames)
+    if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[3] != 3:
+        raise ValueError(f"expected uint8 (n,H,W,3), got {frames.dtype} {tuple(frames.shape)}")
+    frames = frames.contiguous()
+    n, h, w, _ = frames.shape
+    ho, wo = int(size[0]), int(size[1])
+    out = torch.empty((n, ho, wo, 3), dtype=torch.uint8, device=dev)
+    nbytes = lib().nqa_resize_pil_workspace_bytes(n, h, w, ho, wo)
+    buf = (ws or Workspace()).get(nbytes, dev)
+    check(lib().nqa_resize_pil_bilinear_u8(ptr(frames), n, h, w, ho, wo, ptr(buf), buf.numel(), ptr(out),
+                                           stream_ptr(dev)))
+    return out

@@ -9,7 +9,7 @@ from typing import Callable, Dict, Optional
 import numpy as np
 import torch
 
-from . import sharding
+from . import prep, sharding
 
 
 def video_columns(name: str, frame_scores: np.ndarray) -> Dict[str, float]:
@@ -26,8 +26,11 @@ def format_frame_scores(frame_scores: np.ndarray) -> str:
 
 @torch.no_grad()
 def score_video(ref: torch.Tensor, render: torch.Tensor, dists_model: Optional[torch.nn.Module] = None,
-                adists_model: Optional[torch.nn.Module] = None, batch_size: int = 32, group=None) -> Dict[str, float]:
-    """Score one video given as two (N,3,H,W) float32 tensors on the GPU.
+                adists_model: Optional[torch.nn.Module] = None, batch_size: int = 32, group=None,
+                policy: Optional[str] = None, keep_aspect_ratio: bool = False) -> Dict[str, float]:
+    """Score one video given as two (N,3,H,W) float32 tensors on the GPU, or -- with `policy` -- as two
+    decoded uint8 (N,H,W,3) frame stacks on the GPU that are prepared per batch on the device
+    (prep.prepare_frames: "interp256" = prep.py:89-95, "pil256" = prepare_image, ...).
 
     Frames are taken in batches of `batch_size`; with torch.distributed initialised, frame
     ranges shard across ranks and the scores are all-gathered once (sharding.py).  Argument
@@ -39,8 +42,14 @@ def score_video(ref: torch.Tensor, render: torch.Tensor, dists_model: Optional[t
     out: Dict[str, float] = {}
 
     def run(model_call: Callable[[torch.Tensor, torch.Tensor], torch.Tensor]) -> np.ndarray:
-        scores = sharding.score_frames_sharded(lambda lo, hi: model_call(ref[lo:hi], render[lo:hi]), n, batch_size,
-                                               ref.device, group)
+        def batch(lo, hi):
+            a, b = ref[lo:hi], render[lo:hi]
+            if policy is not None:
+                a = prep.prepare_frames(a, policy, keep_aspect_ratio=keep_aspect_ratio)
+                b = prep.prepare_frames(b, policy, keep_aspect_ratio=keep_aspect_ratio)
+            return model_call(a, b)
+
+        scores = sharding.score_frames_sharded(batch, n, batch_size, ref.device, group)
         return scores.cpu().numpy()
 
     if adists_model is not None:

@@ -99,11 +99,16 @@ def channel_weights(feats_x):
     return torch.split(wgt, list(CHNS), dim=1)
 
 
-def adists_from_feats(feats_x, feats_y, window_size: int = WINDOW, as_loss: bool = False):
-    """ADISTS.forward after the two pyramids: (B,) scores, or 1-mean(D) if as_loss.  ADISTS.py:147-197."""
+def adists_from_feats(feats_x, feats_y, window_size: int = WINDOW, as_loss: bool = False, as_map: bool = False):
+    """ADISTS.forward after the two pyramids: (B,) scores, or 1-mean(D) if as_loss.  ADISTS.py:147-197.
+
+    as_map=True returns the reference's (B,B,H,W) tensor: D_map_full starts as zeros (B,H,W) (:163)
+    and every stage adds a (B,1,H,W) resized map (:189), so the sum broadcasts to out[i,j] = map[i]."""
     ps_x = compute_prob(feats_x, window_size)
     wl = channel_weights(feats_x)
     d = 0
+    bsz, _, big_h, big_w = feats_x[0].shape
+    d_map_full = torch.zeros([bsz, big_h, big_w])
     for k in range(len(CHNS) - 1, -1, -1):
         fx = F.normalize(feats_x[k], dim=(2, 3))
         fy = F.normalize(feats_y[k], dim=(2, 3))
@@ -125,14 +130,18 @@ def adists_from_feats(feats_x, feats_y, window_size: int = WINDOW, as_loss: bool
         ps = ps_x[k].expand(xm.shape[0], xm.shape[1], -1, -1)
         pt = 1 - ps
         d_map = ((pt * t + ps * s) * wl[k].unsqueeze(3)).sum(1, keepdim=True)
+        if as_map:
+            d_map_full = d_map_full + F.interpolate(d_map, size=(big_h, big_w), mode="bilinear", align_corners=False)
         d = d + d_map.mean([2, 3]).sum(1)
+    if as_map:
+        return 1 - d_map_full
     return 1 - d.mean() if as_loss else 1 - d
 
 
-def adists(x, y, convs, as_loss=False, window_size: int = WINDOW):
-    """ADISTS.forward(x, y, as_loss, as_map=False).  ADISTS.py:137-197.  x drives ps and weights."""
+def adists(x, y, convs, as_loss=False, window_size: int = WINDOW, as_map: bool = False):
+    """ADISTS.forward(x, y, as_loss, as_map).  ADISTS.py:137-197.  x drives ps and weights."""
     assert x.shape == y.shape
     with torch.no_grad():
         fx = vgg_pyramid(x, convs)
         fy = vgg_pyramid(y, convs)
-        return adists_from_feats(fx, fy, window_size, as_loss)
+        return adists_from_feats(fx, fy, window_size, as_loss, as_map)

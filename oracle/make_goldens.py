@@ -47,6 +47,7 @@ ADISTS_CASES = [
     ("20x20", 20, 20, (40, 41), ("noise10", "indep")),       # every stage takes the global fallback
     ("352x336", 352, 336, (60,), ("blur",)),                  # stage 5 is 22x21: windowed everywhere
 ]
+AMAP_CASES = ("64x64", "97x131", "20x20")  # as_map=True goldens (the map of column j = 0; all columns are equal)
 WEIGHT_SEED = 1234
 
 
@@ -122,6 +123,18 @@ def main():
         np.savez(os.path.join(gold, f"adists_{name}.npz"),
                  h=h, w=w, seeds=np.array(seeds), kinds=np.array(kinds), weight_seed=WEIGHT_SEED,
                  score=r_score.numpy(), loss=r_loss.numpy())
+        if name in AMAP_CASES:  # as_map=True (ADISTS.py:188-193): (B,B,H,W), out[i,j] = map[i]
+            with torch.no_grad():
+                r_map = ref_a(x, y, as_loss=False, as_map=True)
+            o_map = adists_oracle.adists(x, y, convs, as_map=True)
+            assert r_map.shape == o_map.shape == (len(seeds), len(seeds), h, w)
+            dm = (o_map - r_map).abs().max().item()
+            assert dm <= 2e-6, f"{name}: A-DISTS map oracle differs from reference by {dm}"
+            assert all(torch.equal(r_map[:, j], r_map[:, 0]) for j in range(r_map.shape[1]))
+            print(f"ADISTS map {name:8s} shape={tuple(r_map.shape)} |oracle-ref|={dm:.2e}")
+            np.savez(os.path.join(gold, f"amap_{name}.npz"),
+                     h=h, w=w, seeds=np.array(seeds), kinds=np.array(kinds), weight_seed=WEIGHT_SEED,
+                     shape=np.array(r_map.shape), map=r_map[:, 0].numpy())
 
     # weight fingerprint so a drift of the generator is caught on the GPU box too
     fp = np.array([[float(np.abs(w_).sum()), float(b_.sum())] for w_, b_ in np_convs])

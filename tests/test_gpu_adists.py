@@ -43,6 +43,27 @@ def test_adists_vs_golden(path, prec, packed, dev):
     assert abs(loss - float(g["loss"])) <= SCORE_TOL[prec]
 
 
+AMAP_GOLD = sorted(glob.glob(os.path.join(GOLDEN, "amap_*.npz")))
+
+
+@pytest.mark.parametrize("prec", ["f32", "f32s"])
+@pytest.mark.parametrize("path", AMAP_GOLD, ids=[os.path.basename(p)[:-4] for p in AMAP_GOLD])
+def test_adists_map_vs_golden(path, prec, packed, dev):
+    """as_map=True: the full-resolution distortion map against the imported reference's."""
+    from nerf_qa_amd import ops, synth
+    g = np.load(path)
+    x, y = synth.frame_batch([int(s) for s in g["seeds"]], int(g["h"]), int(g["w"]), [str(k) for k in g["kinds"]])
+    d, m = ops.adists_forward(torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev), packed[prec], prec,
+                              with_map=True)
+    assert m.shape == g["map"].shape
+    err = np.abs(m.cpu().numpy() - g["map"]).max()
+    print(f"\n{os.path.basename(path)} [{prec}] map range [{g['map'].min():.4f}, {g['map'].max():.4f}] |d|={err:.2e}")
+    assert err <= 1e-4
+    # the score the same call returns is unchanged by asking for the map
+    d0 = ops.adists_forward(torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev), packed[prec], prec)
+    assert torch.equal(d, d0)
+
+
 def test_adists_module_surface(dev):
     import warnings
     from nerf_qa_amd import synth
@@ -57,7 +78,7 @@ def test_adists_module_surface(dev):
     assert abs(m(x, y).item() - s.mean().item()) < 1e-6
     z = m(x, x, as_loss=False)
     assert z.abs().max().item() < 5e-6
-    with pytest.raises(NotImplementedError):
-        m(x, y, as_map=True)
+    amap = m(x, y, as_map=True)  # the reference's (B,B,H,W) broadcast, out[i, j] = map[i]
+    assert amap.shape == (2, 2, 64, 72) and torch.equal(amap[:, 0], amap[:, 1])
     feats = m.forward_once(x)
     assert [f.shape[1] for f in feats] == [3, 64, 128, 256, 512, 512]

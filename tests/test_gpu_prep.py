@@ -1,0 +1,116 @@
+"""Input preparation on the device against its oracle and the real
+third-party code (Pillow, torch's F.interpolate), through the C ABI."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _frames(seed, n, h, w):
+    from nerf_qa_amd import synth
+    u = synth.uniform(seed, n * h * w * 3).reshape(n, h, w, 3)
+    yy = np.linspace(0, 9, h).reshape(1, h, 1, 1)
+    xx = np.linspace(0, 13, w).reshape(1, 1, w, 1)
+    img = 0.5 * u + 0.5 * (0.5 + 0.5 * np.sin(xx) * np.cos(yy))
+    return (img * 255.999).astype(np.uint8)
+
+
+@pytest.mark.parametrize("roundtrip", [False, True])
+def test_to_tensor(roundtrip, dev):
+    from nerf_qa_amd import ops
+    from oracle import prep_oracle
+    f = _frames(1, 2, 37, 53)
+    f[0, :16, :16, 0] = np.arange(256, dtype=np.uint8).reshape(16, 16)  # every grey level
+    want = prep_oracle.to_tensor_roundtrip(f) if roundtrip else prep_oracle.to_tensor(f)
+    got = ops.u8hwc_to_f32nchw(torch.from_numpy(f).to(dev), pil_roundtrip=roundtrip).cpu()
+    assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("hin,win,size", [
+    (300, 400, (256, 256)), (1080, 1920, (256, 256)), (1080, 1920, 256), (37, 53, (64, 80)), (90, 61, (45, 61)),
+    (64, 64, (224, 224)), (513, 700, (192, 341)), (5, 7, (1, 1)), (1, 1, (4, 3))])
+def test_interpolate_bilinear(hin, win, size, dev):
+    """F.interpolate(..., mode='bilinear', align_corners=False) exactly as the reference calls it."""
+    from nerf_qa_amd import ops
+    from oracle import prep_oracle
+    x = prep_oracle.to_tensor(_frames(hin + win, 2, hin, win))
+    want = prep_oracle.interp(x, size)
+    got = ops.resize_bilinear_f32(x.to(dev), size).cpu()
+    assert got.shape == want.shape
+    assert (got - want).abs().max().item() <= 1e-6
+
+
+@pytest.mark.parametrize("hin,win,hout,wout", [
+    (300, 400, 256, 256), (300, 400, 256, 341), (1080, 1920, 256, 455), (1080, 1920, 256, 256), (37, 53, 64, 80),
+    (90, 61, 45, 61), (257, 258, 256, 256), (64, 64, 64, 32), (513, 700, 256, 349), (40, 30, 41, 29), (33, 33, 33, 33)])
+def test_pil_resize_bit_exact(hin, win, hout, wout, dev):
+    """Pillow's Image.resize(BILINEAR): the device result equals both the installed Pillow and the oracle."""
+    from PIL import Image
+    from nerf_qa_amd import ops
+    from oracle import prep_oracle
+    f = _frames(hin * 3 + wout, 2, hin, win)
+    got = ops.resize_pil_bilinear_u8(torch.from_numpy(f).to(dev), (hout, wout)).cpu().numpy()
+    assert got.shape == (2, hout, wout, 3)
+    for i in range(2):
+        want = np.asarray(Image.fromarray(f[i]).resize((wout, hout), Image.BILINEAR))
+        assert np.array_equal(got[i], want), f"frame {i}: {np.abs(got[i].astype(int) - want).max()} levels off Pillow"
+        assert np.array_equal(got[i], prep_oracle.pil_resize_bilinear_u8(f[i], (hout, wout)))
+
+
+def test_policies_end_to_end(dev):
+    """prepare_frames policy by policy against the reference's host expressions, then into DISTS."""
+    import warnings
+    from PIL import Image
+    from nerf_qa_amd import prep
+    from nerf_qa_amd.DISTS_pytorch import DISTS
+    from nerf_qa_amd.DISTS_pytorch.DISTS_pt import prepare_image
+    from oracle import prep_oracle
+    ref = _frames(5, 2, 540, 960)
+    ren = np.clip(ref.astype(np.int16) + (_frames(6, 2, 540, 960) >> 4) - 8, 0, 255).astype(np.uint8)
+    d_ref, d_ren = torch.from_numpy(ref).to(dev), torch.from_numpy(ren).to(dev)
+    # prep.py:89-95
+    want = prep_oracle.interp(prep_oracle.to_tensor_roundtrip(ref), (256, 256))
+    got = prep.prepare_frames(d_ref, "interp256")
+    assert got.shape == (2, 3, 256, 256) and (got.cpu() - want).abs().max().item() <= 1e-6
+    # test2_prep.py:424-437
+    h, w = prep.equal_pixel_size(540, 960)
+    got = prep.prepare_frames(d_ref, "equal_pixels")
+    assert (got.cpu() - prep_oracle.interp(prep_oracle.to_tensor(ref), (h, w))).abs().max().item() <= 1e-6
+    # DISTS_pt.py:210-217, both aspect policies: bit-exact against the host path through Pillow
+    for keep in (False, True):
+        got = prep.prepare_frames(d_ren, "pil256", keep_aspect_ratio=keep).cpu()
+        want = torch.cat([prepare_image(Image.fromarray(ren[i]), resize=True, keep_aspect_ratio=keep) for i in range(2)])
+        assert got.shape == want.shape and torch.equal(got, want)
+    assert torch.equal(prep.prepare_frames(d_ref, "full").cpu(), prep_oracle.to_tensor(ref))
+    # the metric sees the same input either way
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = DISTS().to(dev).eval()
+    a = m(prep.prepare_frames(d_ref, "pil256"), prep.prepare_frames(d_ren, "pil256"))
+    host = lambda fr: torch.cat([prepare_image(Image.fromarray(fr[i])) for i in range(2)]).to(dev)
+    b = m(host(ref), host(ren))
+    assert torch.equal(a, b)
+
+
+def test_score_video_from_uint8_frames(dev):
+    """The harness accepts decoded uint8 frames and prepares them per batch on the device."""
+    import warnings
+    from nerf_qa_amd import prep, video
+    from nerf_qa_amd.DISTS_pytorch import DISTS
+    ref = torch.from_numpy(_frames(8, 5, 300, 400)).to(dev)
+    ren = torch.from_numpy(_frames(9, 5, 300, 400)).to(dev)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = DISTS().to(dev).eval()
+    cols = video.score_video(ref, ren, dists_model=m, batch_size=2, policy="interp256")
+    want = m(prep.prepare_frames(ref, "interp256"), prep.prepare_frames(ren, "interp256")).cpu().numpy()
+    assert abs(cols["DISTS"] - float(np.mean(want.astype(np.float64)))) < 1e-6
+    assert abs(cols["DISTS_max"] - float(want.max())) < 1e-6

@@ -77,6 +77,22 @@ def test_project_weights(alpha_beta):
     assert a[:, :3].min().item() > 0.019 and b[:, :3].min().item() > 0.019
 
 
+AMAP_GOLD = sorted(glob.glob(os.path.join(GOLDEN, "amap_*.npz")))
+
+
+@pytest.mark.parametrize("path", AMAP_GOLD, ids=[os.path.basename(p)[:-4] for p in AMAP_GOLD])
+def test_adists_map_oracle_matches_reference_golden(path, oracle_convs):
+    """as_map=True (ADISTS.py:188-193): the (B,B,H,W) broadcast and the per-pair map."""
+    from nerf_qa_amd import synth
+    from oracle import adists_oracle
+    g = np.load(path)
+    x, y = synth.frame_batch([int(s) for s in g["seeds"]], int(g["h"]), int(g["w"]), [str(k) for k in g["kinds"]])
+    m = adists_oracle.adists(torch.from_numpy(x), torch.from_numpy(y), oracle_convs, as_map=True)
+    assert tuple(m.shape) == tuple(g["shape"])
+    for j in range(m.shape[1]):
+        assert np.abs(m[:, j].numpy() - g["map"]).max() <= 2e-6
+
+
 def test_adists_window_switch():
     from oracle import adists_oracle
     assert adists_oracle.windowed(21, 21) and not adists_oracle.windowed(20, 300)
