@@ -162,6 +162,11 @@ int nqa_u8hwc_to_f32nchw(const uint8_t *in, int n, int H, int W, int pil_roundtr
 int nqa_resize_bilinear_f32(const float *in, int planes, int Hin, int Win, int Hout, int Wout, float *out,
                             void *stream);
 
+/* The two steps above fused (uint8 (n,Hin,Win,3) -> float32 (n,3,Hout,Wout)), bit-identical to
+ * running them back to back; reads only the taps it needs. */
+int nqa_u8_resize_bilinear_f32(const uint8_t *in, int n, int Hin, int Win, int Hout, int Wout, float *out,
+                               void *stream);
+
 /* transforms.functional.resize on a PIL image (DISTS_pt.py:213-215, test2_prep.py:112,225) =
  * PIL Image.resize((Wout,Hout), BILINEAR): Pillow's antialiased two-pass 8-bit resampler,
  * bit-exact.  in dev uint8 (n,Hin,Win,3) -> out dev uint8 (n,Hout,Wout,3). */

@@ -43,6 +43,7 @@ _SIGNATURES = {
     "nqa_adists_forward_map": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _sz, _vp, _vp, _vp]),
     "nqa_u8hwc_to_f32nchw": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "nqa_resize_bilinear_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "nqa_u8_resize_bilinear_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "nqa_resize_pil_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "nqa_resize_pil_bilinear_u8": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp]),
     "nqa_set_conv_variant": (_i, [_i]),

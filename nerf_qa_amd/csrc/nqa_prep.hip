@@ -36,8 +36,10 @@ __global__ __launch_bounds__(256) void u8hwc_to_f32nchw_kernel(const uint8_t *__
 // torch's upsample_bilinear2d: src = in/out * (dst + 0.5) - 0.5 clamped at 0, the two taps and
 // their weights in float, rows combined as w0*(row0) + w1*(row1).
 __device__ inline void torch_src(int dst, int in, int out, int &i0, int &i1, float &l0, float &l1) {
+  // one fused multiply-add, as torch's CPU kernel evaluates it (a separately rounded product moves
+  // src by an ulp, i.e. the tap weights by ~3e-5 at 1080p)
   const float scale = (float)in / (float)out;
-  float src = scale * ((float)dst + 0.5f) - 0.5f;
+  float src = fmaf(scale, (float)dst + 0.5f, -0.5f);
   src = src < 0.f ? 0.f : src;
   i0 = (int)src;
   if (i0 > in - 1) i0 = in - 1;
@@ -47,6 +49,7 @@ __device__ inline void torch_src(int dst, int in, int out, int &i0, int &i1, flo
 }
 __global__ __launch_bounds__(256) void resize_bilinear_f32_kernel(const float *__restrict__ in, int Hin, int Win,
                                                                   int Hout, int Wout, float *__restrict__ out) {
+#pragma clang fp contract(off)  // plain float products and sums, so the fused kernel below matches bit for bit
   const int plane = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
   if (i >= Hout * Wout) return;
   const int y = i / Wout, x = i - y * Wout;
@@ -57,6 +60,31 @@ __global__ __launch_bounds__(256) void resize_bilinear_f32_kernel(const float *_
   const float *p = in + (size_t)plane * Hin * Win;
   out[(size_t)plane * Hout * Wout + i] = ly0 * (lx0 * p[y0 * Win + x0] + lx1 * p[y0 * Win + x1]) +
                                          ly1 * (lx0 * p[y1 * Win + x0] + lx1 * p[y1 * Win + x1]);
+}
+
+// ToTensor + F.interpolate in one pass: only the four taps of every output pixel are read, and the
+// full-resolution float tensor (12 bytes per source pixel, written then re-read) never exists.
+// Each tap is converted as ToTensor would ((float)v / 255), so the result is bit-identical to
+// running the two kernels above back to back.
+__global__ __launch_bounds__(256) void u8_resize_bilinear_kernel(const uint8_t *__restrict__ in, int Hin, int Win,
+                                                                 int Hout, int Wout, float *__restrict__ out) {
+#pragma clang fp contract(off)
+  const int n = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= Hout * Wout) return;
+  const int y = i / Wout, x = i - y * Wout;
+  int y0, y1, x0, x1;
+  float ly0, ly1, lx0, lx1;
+  torch_src(y, Hin, Hout, y0, y1, ly0, ly1);
+  torch_src(x, Win, Wout, x0, x1, lx0, lx1);
+  const uint8_t *p = in + (size_t)n * Hin * Win * 3;
+  const uint8_t *p00 = p + ((size_t)y0 * Win + x0) * 3, *p01 = p + ((size_t)y0 * Win + x1) * 3;
+  const uint8_t *p10 = p + ((size_t)y1 * Win + x0) * 3, *p11 = p + ((size_t)y1 * Win + x1) * 3;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float a = (float)p00[c] / 255.0f, b = (float)p01[c] / 255.0f;
+    const float cc = (float)p10[c] / 255.0f, d = (float)p11[c] / 255.0f;
+    out[((size_t)n * 3 + c) * Hout * Wout + i] = ly0 * (lx0 * a + lx1 * b) + ly1 * (lx0 * cc + lx1 * d);
+  }
 }
 
 // ---- PIL Image.resize(BILINEAR), uint8 ----------------------------------------------------------
@@ -177,6 +205,17 @@ int nqa_resize_bilinear_f32(const float *in, int planes, int Hin, int Win, int H
   TimedLaunch t(NQA_K_PREP, st);
   resize_bilinear_f32_kernel<<<dim3(cdiv(Hout * Wout, 256), planes), 256, 0, st>>>(in, Hin, Win, Hout, Wout, out);
   return check_launch("resize_bilinear_f32");
+}
+
+int nqa_u8_resize_bilinear_f32(const uint8_t *in, int n, int Hin, int Win, int Hout, int Wout, float *out,
+                               void *stream) {
+  if (bad_img("u8_resize_bilinear_f32", in, out, n, Hin, Win) ||
+      bad_img("u8_resize_bilinear_f32", in, out, n, Hout, Wout))
+    return NQA_E_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  TimedLaunch t(NQA_K_PREP, st);
+  u8_resize_bilinear_kernel<<<dim3(cdiv(Hout * Wout, 256), n), 256, 0, st>>>(in, Hin, Win, Hout, Wout, out);
+  return check_launch("u8_resize_bilinear_f32");
 }
 
 size_t nqa_resize_pil_workspace_bytes(int n, int Hin, int Win, int Hout, int Wout) {

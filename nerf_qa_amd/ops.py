@@ -269,6 +269,19 @@ def resize_bilinear_f32(x: torch.Tensor, size) -> torch.Tensor:
     return out
 
 
+def u8_resize_bilinear_f32(frames: torch.Tensor, size) -> torch.Tensor:
+    """ToTensor + F.interpolate(bilinear, align_corners=False) fused: uint8 (n,H,W,3) -> float32 (n,3,h,w)."""
+    dev = _need_cuda(frames)
+    if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[3] != 3:
+        raise ValueError(f"expected uint8 (n,H,W,3), got {frames.dtype} {tuple(frames.shape)}")
+    frames = frames.contiguous()
+    ho, wo = (int(size), int(size)) if isinstance(size, int) else (int(size[0]), int(size[1]))
+    n, h, w, _ = frames.shape
+    out = torch.empty((n, 3, ho, wo), dtype=torch.float32, device=dev)
+    check(lib().nqa_u8_resize_bilinear_f32(ptr(frames), n, h, w, ho, wo, ptr(out), stream_ptr(dev)))
+    return out
+
+
 def resize_pil_bilinear_u8(frames: torch.Tensor, size, ws: Workspace | None = None) -> torch.Tensor:
     """PIL Image.resize((W,H), BILINEAR) on uint8 (n,H,W,3) frames, bit-exact; size = (Hout, Wout)."""
     dev = _need_cuda(frames)

@@ -57,13 +57,15 @@ def prepare_frames(frames_u8: torch.Tensor, policy: str = "interp256", size=None
     """uint8 (n,H,W,3) on the GPU -> float32 (n,3,h,w) per the named reference policy."""
     n, oh, ow, _ = frames_u8.shape
     if policy == "interp256":
-        return ops.resize_bilinear_f32(ops.u8hwc_to_f32nchw(frames_u8, pil_roundtrip=True), (256, 256))
+        # (the ToPILImage -> ToTensor round trip of :90-91 is the identity in float32, see
+        # tests/test_prep_oracle.py, so the fused ToTensor+interpolate kernel is exact here)
+        return ops.u8_resize_bilinear_f32(frames_u8, (256, 256))
     if policy == "interp":
         if size is None:
             raise ValueError("policy 'interp' needs size=(H, W) or an int")
-        return ops.resize_bilinear_f32(ops.u8hwc_to_f32nchw(frames_u8), size)
+        return ops.u8_resize_bilinear_f32(frames_u8, size)
     if policy == "equal_pixels":
-        return ops.resize_bilinear_f32(ops.u8hwc_to_f32nchw(frames_u8), equal_pixel_size(oh, ow))
+        return ops.u8_resize_bilinear_f32(frames_u8, equal_pixel_size(oh, ow))
     if policy == "pil256":
         h, w = pil_resize_size(oh, ow, keep_aspect_ratio)
         if (h, w) != (oh, ow):

@@ -46,6 +46,9 @@ def test_interpolate_bilinear(hin, win, size, dev):
     got = ops.resize_bilinear_f32(x.to(dev), size).cpu()
     assert got.shape == want.shape
     assert (got - want).abs().max().item() <= 1e-6
+    # the fused uint8 -> resized float kernel is bit-identical to ToTensor followed by the resize
+    fused = ops.u8_resize_bilinear_f32(torch.from_numpy(_frames(hin + win, 2, hin, win)).to(dev), size).cpu()
+    assert torch.equal(fused, got)
 
 
 @pytest.mark.parametrize("hin,win,hout,wout", [
@@ -111,6 +114,6 @@ def test_score_video_from_uint8_frames(dev):
         warnings.simplefilter("ignore")
         m = DISTS().to(dev).eval()
     cols = video.score_video(ref, ren, dists_model=m, batch_size=2, policy="interp256")
-    want = m(prep.prepare_frames(ref, "interp256"), prep.prepare_frames(ren, "interp256")).cpu().numpy()
+    want = m(prep.prepare_frames(ref, "interp256"), prep.prepare_frames(ren, "interp256")).detach().cpu().numpy()
     assert abs(cols["DISTS"] - float(np.mean(want.astype(np.float64)))) < 1e-6
     assert abs(cols["DISTS_max"] - float(want.max())) < 1e-6
