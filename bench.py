@@ -109,7 +109,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="256",
                     help="256 (default, BASELINE configs[1]) | 1080p | adists1080p | adists256")
-    ap.add_argument("--precision", default=None, help="f16 (DISTS default), f32 (A-DISTS default), f32s, bf16")
+    ap.add_argument("--precision", default=None, help="f16 (DISTS default), f32s (A-DISTS default), f32, bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=0, help="override pairs per GPU per step (experiments only)")
     args = ap.parse_args()

@@ -23,6 +23,11 @@
  *   - activations inside the pyramid are NHWC in the element type of the chosen
  *     precision (`prec`): NQA_PREC_F32 / NQA_PREC_F32S float, NQA_PREC_BF16 bfloat16,
  *     NQA_PREC_F16 IEEE half.  All accumulation and all statistics are float32/float64;
+ *   - in NQA_PREC_F32S the maps BETWEEN conv layers (the outputs of nqa_conv1_1, of the
+ *     non-tapped conv layers and of nqa_l2pool) are "split16": per pixel and per group of 16
+ *     channels 64 bytes [hi 0-7 | hi 8-15 | lo 0-7 | lo 8-15], hi = half(v), lo = half(v - hi),
+ *     4 bytes per element like float; the tapped maps (conv layers 1, 3, 6, 9, 12 = relu1_2 ..
+ *     relu5_3) are plain float.  nqa_split16_encode / _decode convert;
  *   - VGG weights are handed over once as a packed blob (nqa_pack_vgg_weights).
  */
 #ifndef NQA_H
@@ -73,7 +78,7 @@ int nqa_pack_vgg_weights(const float *const w_host[NQA_NUM_CONVS], const float *
 
 /* conv1_1 with the input normalisation folded in front: h=(x-mean)/std (DISTS_pt.py:92),
  * zero padding applied to h, conv3x3(3->64)+bias+ReLU (features[0,1]).  x: dev float32
- * NCHW (n,3,H,W); out: dev NHWC (n,H,W,64) in prec's element type. */
+ * NCHW (n,3,H,W); out: dev NHWC (n,H,W,64) in prec's element type (split16 in NQA_PREC_F32S). */
 int nqa_conv1_1(const float *x_nchw, int n, int H, int W, const void *packed_w, int prec, void *out_nhwc,
                 void *stream);
 
@@ -84,18 +89,24 @@ int nqa_conv1_fused(const float *x_nchw, int n, int H, int W, const void *packed
                     void *stream);
 
 /* conv3x3 stride 1 pad 1 + bias + ReLU for VGG layer `layer` (1..12), NHWC in/out
- * (torchvision Conv2d+ReLU pairs, DISTS_pt.py:36-49). */
+ * (torchvision Conv2d+ReLU pairs, DISTS_pt.py:36-49).  NQA_PREC_F32S: split16 in; float out for
+ * the tapped layers (1, 3, 6, 9, 12), split16 out otherwise. */
 int nqa_conv3x3_relu(const void *in_nhwc, int n, int H, int W, int layer, const void *packed_w, int prec,
                      void *out_nhwc, void *stream);
 
 /* L2pooling.forward, DISTS_pt.py:22-25 (= Downsample, ADISTS.py:28-31):
  * sqrt(depthwise 3x3 Hanning, stride 2, pad 1, of x^2, + 1e-12).  NHWC (n,H,W,C) ->
- * (n,ceil(H/2),ceil(W/2),C). */
+ * (n,ceil(H/2),ceil(W/2),C).  NQA_PREC_F32S: float in (a tapped map), split16 out. */
 int nqa_l2pool(const void *in_nhwc, int n, int H, int W, int C, int prec, void *out_nhwc, void *stream);
 
 /* NHWC (prec element type) -> float32 NCHW, so forward_once can return the
  * reference's tensor format (DISTS_pt.py:103). */
 int nqa_nhwc_to_nchw_f32(const void *in_nhwc, int n, int H, int W, int C, int prec, float *out_nchw, void *stream);
+
+/* float32 NHWC (pixels, C) <-> split16 (see Layouts), C a multiple of 16.  Used by the
+ * single-operator parity tests in NQA_PREC_F32S; the fused paths never call them. */
+int nqa_split16_encode(const float *in_nhwc, long pixels, int C, void *out, void *stream);
+int nqa_split16_decode(const void *in, long pixels, int C, float *out_nhwc, void *stream);
 
 /* ---- the fused paths --------------------------------------------------------- */
 

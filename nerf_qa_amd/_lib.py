@@ -31,6 +31,8 @@ _SIGNATURES = {
     "nqa_conv3x3_relu": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     "nqa_l2pool": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "nqa_nhwc_to_nchw_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "nqa_split16_encode": (_i, [_vp, C.c_long, _i, _vp, _vp]),
+    "nqa_split16_decode": (_i, [_vp, C.c_long, _i, _vp, _vp]),
     "nqa_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "nqa_vgg_pyramid": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _sz, C.POINTER(_vp), _vp]),
     "nqa_dists_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _sz, _vp, _vp, _vp]),

@@ -49,9 +49,13 @@ struct PrecF32 {
     return c;
   }
 };
-// float storage like PrecF32, but the convolutions run on the f16 MFMA with both operands split
-// into f16 (hi, lo) pairs: a*b ~= ah*bh + ah*bl + al*bh (the dropped al*bl is ~2^-22 relative).
-// Weights are pre-split at pack time; activations are split in registers after the LDS read.
+// NQA_PREC_F32S: float precision carried as f16 (hi, lo) pairs so the convolutions run on the f16
+// MFMA: a*b ~= ah*bh + ah*bl + al*bh (the dropped al*bl is ~2^-22 relative).  Weights are split
+// at pack time.  Activations BETWEEN conv layers live in the "split16" format, written by the
+// producing kernel's epilogue: 16 channels = 64 bytes [hi 0-7 | hi 8-15 | lo 0-7 | lo 8-15],
+// hi = f16(v), lo = f16(v - hi) -- 4 bytes per element like float, same row layout as the packed
+// weights, so both MFMA operands are plain 16-byte LDS reads.  The tapped maps (relu1_2 ... relu5_3,
+// read by the statistics / pooling / A-DISTS kernels) are plain float.
 struct PrecF32S : PrecF32 {
   static constexpr int ID = NQA_PREC_F32S;
   static constexpr bool SPLIT = true;
@@ -83,11 +87,35 @@ struct PrecF16 {
   }
 };
 
+// split16 store of the 4 consecutive channels c..c+3 (c % 4 == 0) of the pixel record at `pixel`
+__device__ static inline void store_split4(char *pixel, int c, float v0, float v1, float v2, float v3) {
+  typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+  const h4 hi = {(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
+  const h4 lo = {(_Float16)(v0 - (float)hi[0]), (_Float16)(v1 - (float)hi[1]), (_Float16)(v2 - (float)hi[2]),
+                 (_Float16)(v3 - (float)hi[3])};
+  char *p = pixel + (c >> 4) * 64 + ((c >> 3) & 1) * 16 + (c & 7) * 2;
+  *reinterpret_cast<h4 *>(p) = hi;
+  *reinterpret_cast<h4 *>(p + 32) = lo;
+}
+// store one P::CPC-channel group (channels c..) of a pixel in the activation format `P` writes
+template <typename P>
+__device__ static inline void store_group(typename P::T *pixel, int c, const float (&v)[P::CPC]) {
+  if constexpr (P::SPLIT) {
+    store_split4(reinterpret_cast<char *>(pixel), c, v[0], v[1], v[2], v[3]);
+  } else {
+    typedef __attribute__((ext_vector_type(P::CPC))) typename P::T tvec;
+    tvec o;
+#pragma unroll
+    for (int e = 0; e < P::CPC; ++e) o[e] = P::from_f(v[e]);
+    *reinterpret_cast<tvec *>(pixel + c) = o;
+  }
+}
+
 __host__ __device__ static inline size_t prec_elem_bytes(int prec) {
   return prec == NQA_PREC_F32 || prec == NQA_PREC_F32S ? 4 : 2;
 }
 static inline bool prec_valid(int prec) { return prec >= NQA_PREC_F32 && prec <= NQA_PREC_F32S; }
-// the precision every non-conv kernel sees: f32s activations are plain float
+// the precision the kernels that READ tapped maps see: in f32s those are plain float
 static inline int storage_prec(int prec) { return prec == NQA_PREC_F32S ? NQA_PREC_F32 : prec; }
 
 // ---- VGG plan --------------------------------------------------------------------

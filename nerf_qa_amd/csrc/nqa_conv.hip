@@ -76,7 +76,12 @@ __global__ __launch_bounds__(256) void conv1_1_kernel(const float *__restrict__ 
         for (int j = 0; j < 16; ++j) acc[j] = fmaf(in[k], w[k * 64 + c0 + j], acc[j]);
       }
       T *row = reinterpret_cast<T *>(tile + tid * PITCH) + g * 16;
-      if constexpr (sizeof(T) == 4) {
+      if constexpr (P::SPLIT) {  // one split16 record (64 B) per 16 channels, same bytes per pass as float
+#pragma unroll
+        for (int j = 0; j < 16; j += 4)
+          store_split4(reinterpret_cast<char *>(row), j, fmaxf(acc[j], 0.f), fmaxf(acc[j + 1], 0.f),
+                       fmaxf(acc[j + 2], 0.f), fmaxf(acc[j + 3], 0.f));
+      } else if constexpr (sizeof(T) == 4) {
 #pragma unroll
         for (int j = 0; j < 16; j += 4) {
           f32x4 v = {fmaxf(acc[j], 0.f), fmaxf(acc[j + 1], 0.f), fmaxf(acc[j + 2], 0.f), fmaxf(acc[j + 3], 0.f)};
@@ -156,7 +161,7 @@ struct ConvGeom {
 template <typename P, int WAVES_N, int WAVES_M, int WN_T, int WM_T, int TW>
 __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void conv3x3_igemm_kernel(
     const typename P::T *__restrict__ in, const char *__restrict__ wpk, const float *__restrict__ bias,
-    typename P::T *__restrict__ out, int H, int W, int Cin, int Cout, int tiles_x) {
+    typename P::T *__restrict__ out, int H, int W, int Cin, int Cout, int tiles_x, int out_split) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the LDS-DMA builtin exists in the device pass only
   typedef typename P::T T;
   typedef ConvGeom<WAVES_N, WAVES_M, WN_T, WM_T, TW> G;
@@ -310,10 +315,11 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void conv3x3_igemm_kernel(
 #endif
     };
     if constexpr (P::SPLIT) {
-      // split-f16 products: a 64-byte weight row is [hi 0-7 | hi 8-15 | lo 0-7 | lo 8-15] halves of
-      // 16 input channels, a pixel row is the same 16 channels as floats.  One k-step per tap:
-      // lane half h contracts channels 8h..8h+7 (weight chunks h and 2+h, pixel chunks 2h, 2h+1).
-      auto load_split = [&](int kx, u32x4(&ah)[WN_T], u32x4(&al)[WN_T], u32x4(&pr)[WM_T][2]) {
+      // split-f16 products: weight rows and pixel rows are both 16 channels as
+      // [hi 0-7 | hi 8-15 | lo 0-7 | lo 8-15] halves.  One k-step per tap: lane half h contracts
+      // channels 8h..8h+7 (chunk h = hi, chunk 2+h = lo), three MFMAs per tile, taken term by term
+      // so consecutive MFMAs never hit the same accumulator.
+      auto load_split = [&](int kx, u32x4(&ah)[WN_T], u32x4(&al)[WN_T], u32x4(&bh)[WM_T], u32x4(&bl)[WM_T]) {
 #pragma unroll
         for (int i = 0; i < WN_T; ++i) {
           const char *row = wbuf + w_base[i] + kx * 4096;
@@ -323,42 +329,33 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void conv3x3_igemm_kernel(
 #pragma unroll
         for (int j = 0; j < WM_T; ++j) {
           const int q = q0[j] + ky * G::HW_ + kx, sw = (q >> 2) & 3;
-          pr[j][0] = *reinterpret_cast<const u32x4 *>(abuf + q * 64 + (((2 * h) ^ sw) << 4));
-          pr[j][1] = *reinterpret_cast<const u32x4 *>(abuf + q * 64 + (((2 * h + 1) ^ sw) << 4));
+          bh[j] = *reinterpret_cast<const u32x4 *>(abuf + q * 64 + ((h ^ sw) << 4));
+          bl[j] = *reinterpret_cast<const u32x4 *>(abuf + q * 64 + (((2 + h) ^ sw) << 4));
         }
       };
-      auto mma_split = [&](const u32x4(&ah)[WN_T], const u32x4(&al)[WN_T], const u32x4(&pr)[WM_T][2]) {
-        f16x8 bh[WM_T], bl[WM_T];
-#pragma unroll
-        for (int j = 0; j < WM_T; ++j)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float v = __builtin_bit_cast(f32x4, pr[j][e >> 2])[e & 3];
-            const _Float16 hi = (_Float16)v;
-            bh[j][e] = hi;
-            bl[j][e] = (_Float16)(v - (float)hi);
-          }
-        // term by term, so consecutive MFMAs never hit the same accumulator
+      auto mma_split = [&](const u32x4(&ah)[WN_T], const u32x4(&al)[WN_T], const u32x4(&bh)[WM_T],
+                           const u32x4(&bl)[WM_T]) {
 #pragma unroll
         for (int term = 0; term < 3; ++term)
 #pragma unroll
           for (int i = 0; i < WN_T; ++i)
 #pragma unroll
             for (int j = 0; j < WM_T; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, term == 0 ? al[i] : ah[i]),
-                                                                 term == 1 ? bl[j] : bh[j], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                  __builtin_bit_cast(f16x8, term == 0 ? al[i] : ah[i]),
+                  __builtin_bit_cast(f16x8, term == 1 ? bl[j] : bh[j]), acc[i][j], 0, 0, 0);
       };
-      u32x4 ahA[WN_T], alA[WN_T], prA[WM_T][2], ahB[WN_T], alB[WN_T], prB[WM_T][2];
-      load_split(0, ahA, alA, prA);
-      load_split(1, ahB, alB, prB);
+      u32x4 ahA[WN_T], alA[WN_T], bhA[WM_T], blA[WM_T], ahB[WN_T], alB[WN_T], bhB[WM_T], blB[WM_T];
+      load_split(0, ahA, alA, bhA, blA);
+      load_split(1, ahB, alB, bhB, blB);
       __builtin_amdgcn_sched_barrier(0);
-      mma_split(ahA, alA, prA);
+      mma_split(ahA, alA, bhA, blA);
       __builtin_amdgcn_sched_barrier(0);
-      load_split(2, ahA, alA, prA);
+      load_split(2, ahA, alA, bhA, blA);
       __builtin_amdgcn_sched_barrier(0);
-      mma_split(ahB, alB, prB);
+      mma_split(ahB, alB, bhB, blB);
       __builtin_amdgcn_sched_barrier(0);
-      mma_split(ahA, alA, prA);
+      mma_split(ahA, alA, bhA, blA);
       __builtin_amdgcn_sched_barrier(0);
     } else {
     // sched_barrier(0) pins "reads of the next step, then MFMAs of this step": left alone,
@@ -407,8 +404,12 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void conv3x3_igemm_kernel(
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[i][j][4 * g + e] + b4[e], 0.f);
           if constexpr (sizeof(T) == 4) {
-            f32x4 s4 = {v[0], v[1], v[2], v[3]};
-            *reinterpret_cast<f32x4 *>(o + co) = s4;
+            if (P::SPLIT && out_split) {  // feeds another conv: split16 record (wave-uniform branch)
+              store_split4(reinterpret_cast<char *>(o - cbase), cbase + co, v[0], v[1], v[2], v[3]);
+            } else {
+              f32x4 s4 = {v[0], v[1], v[2], v[3]};
+              *reinterpret_cast<f32x4 *>(o + co) = s4;
+            }
           } else {
             typedef __attribute__((ext_vector_type(4))) T t4;
             t4 s4 = {P::from_f(v[0]), P::from_f(v[1]), P::from_f(v[2]), P::from_f(v[3])};
@@ -738,7 +739,7 @@ static int launch_conv1_1(const float *x, int n, int H, int W, const char *packe
 
 template <typename P, int WAVES_N, int WAVES_M, int WN_T, int WM_T, int TW>
 static int launch_igemm(const void *in, int n, int H, int W, int cin, int cout, const char *wpk, const float *bias,
-                        void *out, hipStream_t st) {
+                        void *out, int out_split, hipStream_t st) {
   typedef ConvGeom<WAVES_N, WAVES_M, WN_T, WM_T, TW> G;
   static bool attr_done = false;
   if (!attr_done) {
@@ -754,7 +755,7 @@ static int launch_igemm(const void *in, int n, int H, int W, int cin, int cout, 
   TimedLaunch t(NQA_K_CONV, st);
   conv3x3_igemm_kernel<P, WAVES_N, WAVES_M, WN_T, WM_T, TW><<<grid, G::THREADS, G::LDS_BYTES, st>>>(
       reinterpret_cast<const typename P::T *>(in), wpk, bias, reinterpret_cast<typename P::T *>(out), H, W, cin, cout,
-      tiles_x);
+      tiles_x, out_split);
   return check_launch("conv3x3_igemm");
 }
 
@@ -764,6 +765,7 @@ static int launch_conv(const void *in, int n, int H, int W, int layer, const cha
   const char *wpk = packed + layer_offset(layer, P::ID);
   const float *bias = reinterpret_cast<const float *>(packed + layer_bias_offset(layer, P::ID));
   const bool narrow = W <= 16;  // 32-wide tiles would be half empty
+  const int out_split = P::SPLIT && !cs.last;  // f32s: tapped layers leave as float, the others as split16
   // 8-wave 256 ch x 256 px tiles run ~10 % faster per FLOP than 4-wave 128 x 128 tiles on layers
   // with >= 256 output channels (measured), unless their coarser pixel tiling wastes more than half
   // of that on the map's ragged edge (e.g. 68x120) or the map is narrow.  (An 8-wave 128 ch x 256 px
@@ -775,8 +777,8 @@ static int launch_conv(const void *in, int n, int H, int W, int layer, const cha
     big = eff_big * 1.05 >= eff_small;
   }
 #define NQA_GO(WN, WM, TN, TM)                                                                           \
-  return narrow ? launch_igemm<P, WN, WM, TN, TM, 16>(in, n, H, W, cs.cin, cs.cout, wpk, bias, out, st) \
-                : launch_igemm<P, WN, WM, TN, TM, 32>(in, n, H, W, cs.cin, cs.cout, wpk, bias, out, st)
+  return narrow ? launch_igemm<P, WN, WM, TN, TM, 16>(in, n, H, W, cs.cin, cs.cout, wpk, bias, out, out_split, st) \
+                : launch_igemm<P, WN, WM, TN, TM, 32>(in, n, H, W, cs.cin, cs.cout, wpk, bias, out, out_split, st)
   if (cs.cout == 64) { NQA_GO(1, 4, 2, 2); }                    // 64 ch x 256 px, 4 waves
   if (!big || P::SPLIT) { NQA_GO(2, 2, 2, 2); }                 // 128 ch x 128 px, 4 waves
   if constexpr (!P::SPLIT) {  // (split mode keeps two fragment sets of 3 operands: 4-wave tiles only)
@@ -834,9 +836,9 @@ int conv1_fused(const float *x, const float *y, int B, int n, int H, int W, cons
 }
 
 int conv1_1(const float *x, int n, int H, int W, const void *packed, int prec, void *out, hipStream_t st) {
-  prec = storage_prec(prec);
   const char *p = static_cast<const char *>(packed);
   switch (prec) {
+    case NQA_PREC_F32S: return launch_conv1_1<PrecF32S>(x, n, H, W, p, out, st);  // split16 out
     case NQA_PREC_F32: return launch_conv1_1<PrecF32>(x, n, H, W, p, out, st);
     case NQA_PREC_BF16: return launch_conv1_1<PrecBF16>(x, n, H, W, p, out, st);
     case NQA_PREC_F16: return launch_conv1_1<PrecF16>(x, n, H, W, p, out, st);

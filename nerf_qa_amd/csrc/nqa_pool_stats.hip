@@ -52,10 +52,9 @@ __global__ __launch_bounds__(256) void l2pool_kernel(const typename P::T *__rest
       }
     }
   }
-  tvec o;
 #pragma unroll
-  for (int e = 0; e < P::CPC; ++e) o[e] = P::from_f(sqrtf(acc[e] + 1e-12f));
-  *reinterpret_cast<tvec *>(out + (((size_t)n * Ho + oy) * Wo + ox) * C + g * P::CPC) = o;
+  for (int e = 0; e < P::CPC; ++e) acc[e] = sqrtf(acc[e] + 1e-12f);
+  store_group<P>(out + (((size_t)n * Ho + oy) * Wo + ox) * C, g * P::CPC, acc);
 }
 
 // ---------------------------------------------------------------------------------
@@ -141,8 +140,8 @@ __global__ __launch_bounds__(256) void pool_stats_kernel(const typename P::T *__
   const int oy0 = by * TR, ox0 = bx * TC, tile_units = TR * TC;
   const T *fx = feat + (size_t)b * H * W * C + g * P::CPC;
   const T *fy = feat + (size_t)(B + b) * H * W * C + g * P::CPC;
-  T *ox_ = pooled + (size_t)b * HoWo * C + g * P::CPC;
-  T *oy_ = pooled + (size_t)(B + b) * HoWo * C + g * P::CPC;
+  T *ox_ = pooled + (size_t)b * HoWo * C;
+  T *oy_ = pooled + (size_t)(B + b) * HoWo * C;
   ShiftedMoments<P::CPC> m;
   m.init();
   if (pl < tile_units) {  // pivot = a sample near this thread's first pixel (a window centre, always in range)
@@ -192,14 +191,13 @@ __global__ __launch_bounds__(256) void pool_stats_kernel(const typename P::T *__
         }
       }
     }
-    tvec qx, qy;
 #pragma unroll
     for (int e = 0; e < P::CPC; ++e) {
-      qx[e] = P::from_f(sqrtf(px[e] + 1e-12f));
-      qy[e] = P::from_f(sqrtf(py[e] + 1e-12f));
+      px[e] = sqrtf(px[e] + 1e-12f);
+      py[e] = sqrtf(py[e] + 1e-12f);
     }
-    *reinterpret_cast<tvec *>(ox_ + (size_t)u * C) = qx;
-    *reinterpret_cast<tvec *>(oy_ + (size_t)u * C) = qy;
+    store_group<P>(ox_ + (size_t)u * C, g * P::CPC, px);
+    store_group<P>(oy_ + (size_t)u * C, g * P::CPC, py);
   }
   reduce_store<P::CPC>(m, red, tid, G, PL, C, part + ((size_t)b * nblk + blk) * C * 5);
 }
@@ -369,8 +367,8 @@ static int launch_l2pool(const void *in, int n, int H, int W, int C, void *out, 
 }
 
 int l2pool(const void *in, int n, int H, int W, int C, int prec, void *out, hipStream_t st) {
-  prec = storage_prec(prec);
   switch (prec) {
+    case NQA_PREC_F32S: return launch_l2pool<PrecF32S>(in, n, H, W, C, out, st);  // float in, split16 out
     case NQA_PREC_F32: return launch_l2pool<PrecF32>(in, n, H, W, C, out, st);
     case NQA_PREC_BF16: return launch_l2pool<PrecBF16>(in, n, H, W, C, out, st);
     case NQA_PREC_F16: return launch_l2pool<PrecF16>(in, n, H, W, C, out, st);
@@ -447,8 +445,8 @@ static int launch_pool_stats(const void *feat, int B, int H, int W, int C, void 
 
 // tap (2B images: x then y) -> pooled (2B images) + statistics partials of the B pairs
 int pool_stats(const void *feat, int B, int H, int W, int C, int prec, void *pooled, double *part, hipStream_t st) {
-  prec = storage_prec(prec);
   switch (prec) {
+    case NQA_PREC_F32S: return launch_pool_stats<PrecF32S>(feat, B, H, W, C, pooled, part, st);  // split16 out
     case NQA_PREC_F32: return launch_pool_stats<PrecF32>(feat, B, H, W, C, pooled, part, st);
     case NQA_PREC_BF16: return launch_pool_stats<PrecBF16>(feat, B, H, W, C, pooled, part, st);
     case NQA_PREC_F16: return launch_pool_stats<PrecF16>(feat, B, H, W, C, pooled, part, st);

@@ -87,6 +87,33 @@ __global__ __launch_bounds__(256) void u8_resize_bilinear_kernel(const uint8_t *
   }
 }
 
+// ---- split16 <-> float (NQA_PREC_F32S activation format, nqa_common.h) ---------------------------
+__global__ __launch_bounds__(256) void split16_encode_kernel(const float *__restrict__ in, long groups, int C,
+                                                             char *__restrict__ out) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;  // one 4-channel group
+  if (i >= groups) return;
+  const int G = C / 4;
+  const long pix = i / G;
+  const int c = (int)(i - pix * G) * 4;
+  const f32x4 v = *reinterpret_cast<const f32x4 *>(in + pix * C + c);
+  store_split4(out + pix * C * 4, c, v[0], v[1], v[2], v[3]);
+}
+__global__ __launch_bounds__(256) void split16_decode_kernel(const char *__restrict__ in, long groups, int C,
+                                                             float *__restrict__ out) {
+  typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= groups) return;
+  const int G = C / 4;
+  const long pix = i / G;
+  const int c = (int)(i - pix * G) * 4;
+  const char *p = in + pix * C * 4 + (c >> 4) * 64 + ((c >> 3) & 1) * 16 + (c & 7) * 2;
+  const h4 hi = *reinterpret_cast<const h4 *>(p), lo = *reinterpret_cast<const h4 *>(p + 32);
+  f32x4 v;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = (float)hi[e] + (float)lo[e];
+  *reinterpret_cast<f32x4 *>(out + pix * C + c) = v;
+}
+
 // ---- PIL Image.resize(BILINEAR), uint8 ----------------------------------------------------------
 static constexpr int kPrecBits = 32 - 8 - 2;
 
@@ -216,6 +243,36 @@ int nqa_u8_resize_bilinear_f32(const uint8_t *in, int n, int Hin, int Win, int H
   TimedLaunch t(NQA_K_PREP, st);
   u8_resize_bilinear_kernel<<<dim3(cdiv(Hout * Wout, 256), n), 256, 0, st>>>(in, Hin, Win, Hout, Wout, out);
   return check_launch("u8_resize_bilinear_f32");
+}
+
+static int split16_args(const char *who, const void *in, const void *out, long pixels, int C) {
+  if (!in || !out) {
+    set_error("%s: null pointer", who);
+    return NQA_E_ARG;
+  }
+  if (pixels <= 0 || C <= 0 || C % 16 || pixels * (C / 4) / 256 >= (1L << 31)) {
+    set_error("%s: bad size pixels=%ld C=%d (C must be a multiple of 16)", who, pixels, C);
+    return NQA_E_ARG;
+  }
+  return NQA_OK;
+}
+
+int nqa_split16_encode(const float *in_nhwc, long pixels, int C, void *out, void *stream) {
+  int rc = split16_args("split16_encode", in_nhwc, out, pixels, C);
+  if (rc) return rc;
+  const long groups = pixels * (C / 4);
+  split16_encode_kernel<<<(unsigned)((groups + 255) / 256), 256, 0, static_cast<hipStream_t>(stream)>>>(
+      in_nhwc, groups, C, static_cast<char *>(out));
+  return check_launch("split16_encode");
+}
+
+int nqa_split16_decode(const void *in, long pixels, int C, float *out_nhwc, void *stream) {
+  int rc = split16_args("split16_decode", in, out_nhwc, pixels, C);
+  if (rc) return rc;
+  const long groups = pixels * (C / 4);
+  split16_decode_kernel<<<(unsigned)((groups + 255) / 256), 256, 0, static_cast<hipStream_t>(stream)>>>(
+      static_cast<const char *>(in), groups, C, out_nhwc);
+  return check_launch("split16_decode");
 }
 
 size_t nqa_resize_pil_workspace_bytes(int n, int Hin, int Win, int Hout, int Wout) {

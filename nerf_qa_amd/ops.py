@@ -67,7 +67,12 @@ def pack_vgg_weights(convs: Sequence, prec) -> torch.Tensor:
     return blob
 
 
+TAP_LAYERS = (1, 3, 6, 9, 12)  # conv layers whose output is tapped (relu1_2 .. relu5_3)
+
+
 def conv1_1(x: torch.Tensor, packed: torch.Tensor, prec) -> torch.Tensor:
+    """relu1_1 as NHWC in prec's activation format ("f32s": split16 bytes in a float32 tensor, see
+    include/nqa.h Layouts; split16_decode turns them into floats)."""
     p = prec_id(prec)
     dev = _need_cuda(x, packed)
     x = _f32c(x)
@@ -91,6 +96,7 @@ def conv1_fused(x: torch.Tensor, packed: torch.Tensor, prec) -> torch.Tensor:
 
 
 def conv3x3_relu(inp: torch.Tensor, layer: int, packed: torch.Tensor, prec) -> torch.Tensor:
+    """One VGG conv layer, NHWC.  "f32s": split16 in; float out for TAP_LAYERS, split16 out otherwise."""
     p = prec_id(prec)
     dev = _need_cuda(inp, packed)
     assert inp.dtype == PREC_DTYPE[p] and inp.is_contiguous()
@@ -102,6 +108,7 @@ def conv3x3_relu(inp: torch.Tensor, layer: int, packed: torch.Tensor, prec) -> t
 
 
 def l2pool(inp: torch.Tensor, prec) -> torch.Tensor:
+    """L2-pool of a tapped map, NHWC.  "f32s": float in, split16 out (it feeds the next conv)."""
     p = prec_id(prec)
     dev = _need_cuda(inp)
     assert inp.dtype == PREC_DTYPE[p] and inp.is_contiguous()
@@ -295,4 +302,24 @@ def resize_pil_bilinear_u8(frames: torch.Tensor, size, ws: Workspace | None = No
     buf = (ws or Workspace()).get(nbytes, dev)
     check(lib().nqa_resize_pil_bilinear_u8(ptr(frames), n, h, w, ho, wo, ptr(buf), buf.numel(), ptr(out),
                                            stream_ptr(dev)))
+    return out
+
+
+# ---- split16 (NQA_PREC_F32S activation format between conv layers; tests and tools only) ----------
+def split16_encode(a: torch.Tensor) -> torch.Tensor:
+    """float32 NHWC (..., C) -> split16 bytes viewed as float32 of the same shape (4 bytes per element)."""
+    dev = _need_cuda(a)
+    a = _f32c(a)
+    c = a.shape[-1]
+    out = torch.empty_like(a)
+    check(lib().nqa_split16_encode(ptr(a), a.numel() // c, c, ptr(out), stream_ptr(dev)))
+    return out
+
+
+def split16_decode(a: torch.Tensor) -> torch.Tensor:
+    dev = _need_cuda(a)
+    assert a.dtype == torch.float32 and a.is_contiguous()
+    c = a.shape[-1]
+    out = torch.empty_like(a)
+    check(lib().nqa_split16_decode(ptr(a), a.numel() // c, c, ptr(out), stream_ptr(dev)))
     return out

@@ -36,6 +36,12 @@ def _rand(shape, seed, lo=0.0, hi=1.0):
     return torch.from_numpy((synth.uniform(seed, n) * (hi - lo) + lo).astype(np.float32).reshape(shape))
 
 
+def _floats(out, prec, split):
+    """Activation tensor -> float32; in f32s the maps between conv layers are split16-encoded."""
+    from nerf_qa_amd import ops
+    return ops.split16_decode(out) if (prec == "f32s" and split) else out.float()
+
+
 def _close(got, ref, rtol, what):
     scale = ref.abs().max().item() + 1e-30
     err = (got - ref).abs().max().item()
@@ -54,7 +60,7 @@ def test_conv1_1(prec, shape, np_convs, packed, dev):
     ref = F.relu(F.conv2d((x - mean) / std, w, b, padding=1))
     out = ops.conv1_1(x.to(dev), packed[prec], prec)
     assert out.dtype == DT[prec] and out.shape == (shape[0], shape[2], shape[3], 64)
-    got = out.float().permute(0, 3, 1, 2).cpu()
+    got = _floats(out, prec, True).permute(0, 3, 1, 2).cpu()
     _close(got, ref, OUT_RTOL[prec], f"conv1_1[{prec}]")
 
 
@@ -122,8 +128,9 @@ def test_conv3x3_relu(prec, layer, n, h, w, np_convs, packed, dev):
     wq = torch.from_numpy(np_convs[layer][0]).to(DT[prec]).float()
     b = torch.from_numpy(np_convs[layer][1])
     ref = F.relu(F.conv2d(a.float().permute(0, 3, 1, 2), wq, b, padding=1))
-    out = ops.conv3x3_relu(a.to(dev), layer, packed[prec], prec)
-    got = out.float().permute(0, 3, 1, 2).cpu()
+    inp = ops.split16_encode(a.to(dev)) if prec == "f32s" else a.to(dev)
+    out = ops.conv3x3_relu(inp, layer, packed[prec], prec)
+    got = _floats(out, prec, layer not in ops.TAP_LAYERS).permute(0, 3, 1, 2).cpu()
     _close(got, ref, OUT_RTOL[prec], f"conv layer {layer} [{prec}] {n}x{h}x{w}")
 
 
@@ -136,7 +143,7 @@ def test_l2pool(prec, n, h, w, c, dev):
     ref = dists_oracle.l2pool(a.float().permute(0, 3, 1, 2))
     out = ops.l2pool(a.to(dev), prec)
     assert out.shape == (n, (h + 1) // 2, (w + 1) // 2, c)
-    _close(out.float().permute(0, 3, 1, 2).cpu(), ref, OUT_RTOL[prec], f"l2pool[{prec}]")
+    _close(_floats(out, prec, True).permute(0, 3, 1, 2).cpu(), ref, OUT_RTOL[prec], f"l2pool[{prec}]")
 
 
 @pytest.mark.parametrize("prec", PRECS)
@@ -145,6 +152,20 @@ def test_nhwc_to_nchw(prec, dev):
     a = _rand((2, 5, 9, 72), 3).to(DT[prec])
     out = ops.nhwc_to_nchw_f32(a.to(dev), prec).cpu()
     assert torch.equal(out, a.float().permute(0, 3, 1, 2))
+
+
+def test_split16_roundtrip(dev):
+    """split16 = (half hi, half lo) per element: decode(encode(v)) is v to ~2^-21, exact for half-representable v."""
+    from nerf_qa_amd import ops
+    a = _rand((2, 5, 7, 64), 9, 0.0, 300.0)
+    a[0, 0, 0, :8] = torch.tensor([0.0, 1.0, 0.5, 1024.0, 0.75, 65504.0, 2.0 ** -14, 0.333251953125])
+    enc = ops.split16_encode(a.to(dev))
+    back = ops.split16_decode(enc).cpu()
+    assert (back - a).abs().max().item() <= 2.0 ** -21 * 300.0
+    assert torch.equal(back[0, 0, 0, :8], a[0, 0, 0, :8])
+    raw = enc.cpu().view(torch.float16).view(2, 5, 7, 4, 4, 8)  # [..., group of 16 ch, (hi0 hi1 lo0 lo1), 8]
+    hi = raw[..., 0:2, :].reshape(2, 5, 7, 4, 16).reshape(2, 5, 7, 64)
+    assert torch.equal(hi, a.half())
 
 
 def test_stats_nchw_and_score(alpha_beta, dev):
