@@ -780,10 +780,8 @@ static int launch_conv(const void *in, int n, int H, int W, int layer, const cha
   return narrow ? launch_igemm<P, WN, WM, TN, TM, 16>(in, n, H, W, cs.cin, cs.cout, wpk, bias, out, out_split, st) \
                 : launch_igemm<P, WN, WM, TN, TM, 32>(in, n, H, W, cs.cin, cs.cout, wpk, bias, out, out_split, st)
   if (cs.cout == 64) { NQA_GO(1, 4, 2, 2); }                    // 64 ch x 256 px, 4 waves
-  if (!big || P::SPLIT) { NQA_GO(2, 2, 2, 2); }                 // 128 ch x 128 px, 4 waves
-  if constexpr (!P::SPLIT) {  // (split mode keeps two fragment sets of 3 operands: 4-wave tiles only)
-    NQA_GO(2, 4, 4, 2);                                         // 256 ch x 256 px, 8 waves
-  }
+  if (!big) { NQA_GO(2, 2, 2, 2); }                             // 128 ch x 128 px, 4 waves
+  NQA_GO(2, 4, 4, 2);                                           // 256 ch x 256 px, 8 waves
 #undef NQA_GO
 }
 
