@@ -318,13 +318,34 @@ struct Gauss2 {
   float g[42];  // g[t] = gaussian[t mod 21]
 };
 
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+// One DPP move of a float (ctrl is an instruction immediate); lanes outside row_mask get 0.
+template <int CTRL, int ROW_MASK>
+__device__ inline float dpp0(float v) {
+  return __builtin_bit_cast(float,
+                            __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+// Sum over the 64 lanes, valid in lane 63, broadcast through an SGPR: six DPP adds (quad swaps,
+// half-row and row mirrors, then the two row broadcasts) instead of six LDS-crossbar bpermutes.
+__device__ inline float wave_sum(float v) {
+  v += dpp0<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+  v += dpp0<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+  v += dpp0<0x141, 0xF>(v);  // row_half_mirror
+  v += dpp0<0x140, 0xF>(v);  // row_mirror: every lane of a 16-lane row holds the row's sum
+  v += dpp0<0x142, 0xA>(v);  // row_bcast15 into rows 1 and 3
+  v += dpp0<0x143, 0xC>(v);  // row_bcast31 into rows 2 and 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 template <typename P>
 __global__ __launch_bounds__(256, 2) void adists_window_lanes_kernel(
     const typename P::T *__restrict__ fx, const typename P::T *__restrict__ fy, int H, int W, int C,
     const float *__restrict__ q, int B, int ctot, int coff, const float *__restrict__ wgt, Gauss gw,
     const float *__restrict__ g2, float *__restrict__ gamma, float *__restrict__ tw, float *__restrict__ sw) {
   typedef typename P::T T;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // the wave index as a provably uniform value, so the row pointers and loop bounds stay scalar
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.z;
   const int Ho = H - (kWin - 1), Wo = W - (kWin - 1);
   const int ox = blockIdx.x * 4 + wave;  // 4 adjacent columns per block: their neighbour loads overlap in L1
@@ -337,74 +358,81 @@ __global__ __launch_bounds__(256, 2) void adists_window_lanes_kernel(
   for (int cb = 0; cb < C; cb += 64) {
     const int c = cb + lane;
     const float ix = q[0 * st + qo + c], iy = q[1 * st + qo + c], wc = wgt[qo + c];
-    const T *px = fx + ((size_t)(b * H + oy0) * W + ox) * C + c;
-    const T *py = fy + ((size_t)(b * H + oy0) * W + ox) * C + c;
+    const T *px = fx + ((size_t)(b * H + oy0) * W + ox) * C + cb;  // wave-uniform; the lane is added per load
+    const T *py = fy + ((size_t)(b * H + oy0) * W + ox) * C + cb;
     // ring of the last 21 rows' horizontal sums, slot = grp*7 + sub.  The row loop is unrolled by 7
     // so `sub` is a compile-time index; `grp` (0..2) is dynamic and resolved by wave-uniform selects
     // (a switch over 21 slots makes hipcc shuttle the whole ring through AGPRs every row).
-    float r0[3][7], r1[3][7], r2[3][7], r3[3][7], r4[3][7];
+    // The five running sums travel as two float pairs + one float so that the 2 x 21 taps per
+    // (pixel, channel) are packed v_pk_fma_f32 / v_pk_mul_f32: 4 + 3 instructions per tap pair.
+    f32x2 r01[3][7], r23[3][7];
+    float r4[3][7];
 #pragma unroll
     for (int g = 0; g < 3; ++g)
 #pragma unroll
-      for (int u = 0; u < 7; ++u) r0[g][u] = r1[g][u] = r2[g][u] = r3[g][u] = r4[g][u] = 0.f;
+      for (int u = 0; u < 7; ++u) {
+        r01[g][u] = r23[g][u] = (f32x2){0.f, 0.f};
+        r4[g][u] = 0.f;
+      }
     int grp = 0;
     for (int rr0 = 0; rr0 < nrows; rr0 += 7) {
 #pragma unroll
       for (int sub = 0; sub < 7; ++sub) {
         const int rr = rr0 + sub;
         if (rr < nrows) {
-          float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f, h4 = 0.f;
+          // all 42 loads go out back to back before any arithmetic (left to itself hipcc pairs each
+          // load with its use and pays the memory latency 21 times per row)
+          T xr[kWin], yr[kWin];
 #pragma unroll
           for (int j = 0; j < kWin; ++j) {
-            const float xv = P::to_f(px[(size_t)j * C]), yv = P::to_f(py[(size_t)j * C]);
-            const float gx_ = gw.g[j] * xv, gy_ = gw.g[j] * yv;
-            h0 += gx_;
-            h1 += gy_;
-            h2 = fmaf(gx_, xv, h2);
-            h3 = fmaf(gy_, yv, h3);
-            h4 = fmaf(gx_, yv, h4);
+            xr[j] = px[(size_t)j * C + lane];
+            yr[j] = py[(size_t)j * C + lane];
           }
           px += (size_t)W * C;
           py += (size_t)W * C;
+          __builtin_amdgcn_sched_barrier(0);
+          f32x2 h01 = {0.f, 0.f}, h23 = {0.f, 0.f};
+          float h4 = 0.f;
+#pragma unroll
+          for (int j = 0; j < kWin; ++j) {
+            const f32x2 v = {P::to_f(xr[j]), P::to_f(yr[j])};
+            const f32x2 gv = gw.g[j] * v;
+            h01 += gv;
+            h23 = gv * v + h23;
+            h4 = fmaf(gv[0], v[1], h4);
+          }
 #pragma unroll
           for (int g = 0; g < 3; ++g) {
             const bool hit = grp == g;
-            r0[g][sub] = hit ? h0 : r0[g][sub];
-            r1[g][sub] = hit ? h1 : r1[g][sub];
-            r2[g][sub] = hit ? h2 : r2[g][sub];
-            r3[g][sub] = hit ? h3 : r3[g][sub];
+            r01[g][sub] = hit ? h01 : r01[g][sub];
+            r23[g][sub] = hit ? h23 : r23[g][sub];
             r4[g][sub] = hit ? h4 : r4[g][sub];
           }
           if (rr >= kWin - 1) {
             const float *gv = g2 + (kWin - 1 - (grp * 7 + sub));  // weight of ring slot s at this phase
-            float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f;
+            f32x2 m01 = {0.f, 0.f}, m23 = {0.f, 0.f};
+            float m4 = 0.f;
 #pragma unroll
             for (int g = 0; g < 3; ++g)
 #pragma unroll
               for (int u = 0; u < 7; ++u) {
                 const float wv = gv[g * 7 + u];
-                m0 = fmaf(wv, r0[g][u], m0);
-                m1 = fmaf(wv, r1[g][u], m1);
-                m2 = fmaf(wv, r2[g][u], m2);
-                m3 = fmaf(wv, r3[g][u], m3);
+                m01 = wv * r01[g][u] + m01;
+                m23 = wv * r23[g][u] + m23;
                 m4 = fmaf(wv, r4[g][u], m4);
               }
-            float gterm = (m2 - m0 * m0) / (m0 + 1e-12f);
+            const float m0 = m01[0], m1 = m01[1], m2 = m23[0], m3 = m23[1];
+            const float gterm = (m2 - m0 * m0) / (m0 + 1e-12f);
             const float mx = ix * m0, my = iy * m1;
             const float vx = ix * ix * m2 - mx * mx, vy = iy * iy * m3 - my * my;
             const float cov = ix * iy * m4 - mx * my;
-            float tt = wc * ((2.f * mx * my + 1e-6f) / (mx * mx + my * my + 1e-6f));
-            float ss = wc * ((2.f * cov + 1e-6f) / (vx + vy + 1e-6f));
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-              gterm += __shfl_xor(gterm, off, 64);
-              tt += __shfl_xor(tt, off, 64);
-              ss += __shfl_xor(ss, off, 64);
-            }
+            const float tt = wc * ((2.f * mx * my + 1e-6f) / (mx * mx + my * my + 1e-6f));
+            const float ss = wc * ((2.f * cov + 1e-6f) / (vx + vy + 1e-6f));
+            const float gs = wave_sum(gterm), ts = wave_sum(tt), sss = wave_sum(ss);
             if (lane == rr - (kWin - 1)) {
-              acc_g += gterm;
-              acc_t += tt;
-              acc_s += ss;
+              acc_g += gs;
+              acc_t += ts;
+              acc_s += sss;
             }
           }
         }
