@@ -384,39 +384,66 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void conv3x3_igemm_kernel(
   }
 #endif
 
-  // ---- epilogue: bias + ReLU, 4 consecutive output channels per lane per store ----
-  // acc[i][j][r]: channel = 8*(r>>2) + 4*h + (r&3) of row tile i, pixel = lane&31 of column tile j.
+  // ---- epilogue: bias + ReLU, staged through LDS so the tile leaves as whole pixel records ----
+  // acc[i][j][r]: channel = 8*(r>>2) + 4*h + (r&3) of row tile i, pixel = lane&31 of column tile j:
+  // a lane owns 4 consecutive channels of one pixel, i.e. 8- or 16-byte pieces a whole record
+  // (Cout * sizeof(T) bytes) apart -- stored directly, every lane would write its own cache line.
+  // Instead each column tile j goes through LDS (the stage buffers are free now) as
+  // [pixel][this block's RB = BN*sizeof(T) record bytes], 16-byte chunks XOR-swizzled by the row
+  // so both sides are conflict-free, and leaves as 16 bytes per lane with consecutive lanes on
+  // consecutive chunks of one record: full-line writes.
+  constexpr int RB = G::BN * (int)sizeof(T), NCH = RB / 16, SWZ = NCH >= 16 ? 15 : NCH - 1;
+  constexpr int ROWS = WAVES_M * 32;
+  static_assert(ROWS * RB <= G::LDS_BYTES, "epilogue tile does not fit the stage buffers");
+  char *const obase = reinterpret_cast<char *>(out) + (size_t)ct * RB;
+  const size_t rec = (size_t)Cout * sizeof(T);
 #pragma unroll
   for (int j = 0; j < WM_T; ++j) {
-    const int m = (wm * WM_T + j) * 32 + l31;
-    const int ty = m / TW, tx = m - ty * TW;
-    const int gy = y0 + ty, gx = x0 + tx;
-    if (gy < H && gx < W) {
-      const int cbase = ct * G::BN + wn * WN_T * 32 + 4 * h;
-      T *o = out + ((size_t)(n * H + gy) * W + gx) * Cout + cbase;
+    __syncthreads();  // the last stage's LDS reads (or the previous pass's copy-out) are done
+    {
+      const int row = wm * 32 + l31;
+      char *const rbase = smem + row * RB;
+      const int sw = row & SWZ;
 #pragma unroll
       for (int i = 0; i < WN_T; ++i) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int co = i * 32 + 8 * g;
-          const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bias + cbase + co);
+          const int cl = (wn * WN_T + i) * 32 + 8 * g + 4 * h;  // first of this lane's 4 channels, block-local
+          const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bias + ct * G::BN + cl);
           float v[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[i][j][4 * g + e] + b4[e], 0.f);
           if constexpr (sizeof(T) == 4) {
             if (P::SPLIT && out_split) {  // feeds another conv: split16 record (wave-uniform branch)
-              store_split4(reinterpret_cast<char *>(o - cbase), cbase + co, v[0], v[1], v[2], v[3]);
+              typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+              const h4 hi = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+              const h4 lo = {(_Float16)(v[0] - (float)hi[0]), (_Float16)(v[1] - (float)hi[1]),
+                             (_Float16)(v[2] - (float)hi[2]), (_Float16)(v[3] - (float)hi[3])};
+              const int off = (cl >> 4) * 64 + ((cl >> 3) & 1) * 16 + (cl & 7) * 2;
+              *reinterpret_cast<h4 *>(rbase + ((((off >> 4)) ^ sw) << 4) + (off & 15)) = hi;
+              *reinterpret_cast<h4 *>(rbase + ((((off >> 4) + 2) ^ sw) << 4) + (off & 15)) = lo;
             } else {
-              f32x4 s4 = {v[0], v[1], v[2], v[3]};
-              *reinterpret_cast<f32x4 *>(o + co) = s4;
+              const f32x4 s4 = {v[0], v[1], v[2], v[3]};
+              *reinterpret_cast<f32x4 *>(rbase + (((cl >> 2) ^ sw) << 4)) = s4;
             }
           } else {
             typedef __attribute__((ext_vector_type(4))) T t4;
-            t4 s4 = {P::from_f(v[0]), P::from_f(v[1]), P::from_f(v[2]), P::from_f(v[3])};
-            *reinterpret_cast<t4 *>(o + co) = s4;
+            const t4 s4 = {P::from_f(v[0]), P::from_f(v[1]), P::from_f(v[2]), P::from_f(v[3])};
+            *reinterpret_cast<t4 *>(rbase + (((cl >> 3) ^ sw) << 4) + (cl & 4) * 2) = s4;
           }
         }
       }
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int idx = tid; idx < ROWS * NCH; idx += G::THREADS) {
+      const int row = idx / NCH, k = idx - row * NCH;
+      const int m = ((row >> 5) * WM_T + j) * 32 + (row & 31);
+      const int ty = m / TW, tx = m - ty * TW;
+      const int gy = y0 + ty, gx = x0 + tx;
+      if (gy < H && gx < W)
+        *reinterpret_cast<u32x4 *>(obase + ((size_t)(n * H + gy) * W + gx) * rec + k * 16) =
+            *reinterpret_cast<const u32x4 *>(smem + row * RB + ((k ^ (row & SWZ)) << 4));
     }
   }
 #endif
