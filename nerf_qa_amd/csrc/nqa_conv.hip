@@ -751,7 +751,7 @@ extern "C" int nqa_debug_stamps(unsigned long long *out8, int reset) {
 }
 #endif
 
-static int g_conv_variant = 1;  // 0: 4-wave tiles everywhere; 1: 8-wave tiles where the layer is wide enough
+static int g_conv_variant = 2;  // 0: 4-wave tiles everywhere; 1: + 8-wave 256x256 tiles; 2: + 8-wave 128x512 tiles
 void set_conv_variant(int v) { g_conv_variant = v; }
 
 template <typename P>
@@ -797,16 +797,28 @@ static int launch_conv(const void *in, int n, int H, int W, int layer, const cha
   // with >= 256 output channels (measured), unless their coarser pixel tiling wastes more than half
   // of that on the map's ragged edge (e.g. 68x120) or the map is narrow.  (An 8-wave 128 ch x 256 px
   // tile for the 128-channel layers measured 5-9 % SLOWER than the 4-wave tile.)
-  bool big = g_conv_variant == 1 && cs.cout >= 256 && !narrow;
+  bool big = g_conv_variant >= 1 && cs.cout >= 256 && !narrow;
   if (big) {
     const double eff_big = (double)H * W / ((double)cdiv(W, 32) * cdiv(H, 8) * 256.0);
     const double eff_small = (double)H * W / ((double)cdiv(W, 32) * cdiv(H, 4) * 128.0);
     big = eff_big * 1.05 >= eff_small;
   }
-#define NQA_GO(WN, WM, TN, TM)                                                                           \
+  // 8-wave 128 ch x 512 px tiles: the loop is bound by what a CU can take in per clock (weights
+  // 3*BN*64 B + halo per stage), and for the same 64 K accumulators 128 x 512 moves 37.6 KB per
+  // stage where 256 x 256 moves 56 KB and two 128 x 128 blocks move 58 KB.
+  bool wide = g_conv_variant >= 2 && cs.cout >= 128 && !narrow && H >= 12;
+  if (wide) {
+    const double eff_wide = (double)H * W / ((double)cdiv(W, 32) * cdiv(H, 16) * 512.0);
+    const double eff_small = (double)H * W / ((double)cdiv(W, 32) * cdiv(H, 4) * 128.0);
+    wide = eff_wide * 1.10 >= eff_small;
+  }
+#define NQA_GO(WN, WM, TN, TM)                                                                                      \
   return narrow ? launch_igemm<P, WN, WM, TN, TM, 16>(in, n, H, W, cs.cin, cs.cout, wpk, bias, out, out_split, st) \
                 : launch_igemm<P, WN, WM, TN, TM, 32>(in, n, H, W, cs.cin, cs.cout, wpk, bias, out, out_split, st)
   if (cs.cout == 64) { NQA_GO(1, 4, 2, 2); }                    // 64 ch x 256 px, 4 waves
+  if constexpr (!P::SPLIT) {
+    if (wide) return launch_igemm<P, 2, 4, 2, 4, 32>(in, n, H, W, cs.cin, cs.cout, wpk, bias, out, out_split, st);
+  }
   if (!big) { NQA_GO(2, 2, 2, 2); }                             // 128 ch x 128 px, 4 waves
   NQA_GO(2, 4, 4, 2);                                           // 256 ch x 256 px, 8 waves
 #undef NQA_GO

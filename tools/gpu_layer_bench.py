@@ -18,7 +18,7 @@ prec = os.environ.get("NQA_TOOL_PREC", "f16")
 DT = {"f16": torch.float16, "bf16": torch.bfloat16}.get(prec, torch.float32)
 packed = ops.pack_vgg_weights(synth.vgg16_weights(1234), prec).to(dev)
 dims = ops.pyramid_dims(H, W)
-VARIANTS = (0, 1)
+VARIANTS = (0, 1, 2)
 
 
 def time_layer(a, layer, reps):

@@ -12,7 +12,7 @@ L = _lib.lib()
 fn = C.CDLL(_lib.LIB_PATH).nqa_debug_stamps
 buf = (C.c_ulonglong * 8)()
 dims = ops.pyramid_dims(256, 256)
-for layer, variant in ((8, 1), (8, 0), (5, 1), (3, 0), (1, 0)):
+for layer, variant in ((1, 0), (2, 0), (3, 0), (4, 1), (4, 0), (5, 1), (8, 1), (8, 0), (10, 0)):
     ops.set_conv_variant(variant)
     h, w = dims[ops.CONV_STAGE[layer]]
     a = (torch.rand(64, h, w, ops.CONV_CIN[layer], device=dev) - 0.5).clamp_min(0).to(_lib.PREC_DTYPE[_lib.prec_id(PREC)])
