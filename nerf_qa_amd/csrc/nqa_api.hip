@@ -326,7 +326,9 @@ int nqa_pack_vgg_weights(const float *const w_host[NQA_NUM_CONVS], const float *
         for (int t = 0; t < 9; ++t)
           for (int n = 0; n < bn; ++n)
             for (int pos = 0; pos < 4; ++pos) {
-              const int c = pos ^ ((n >> 2) & 3);
+              // chunk swizzle of the MFMA shape that reads the layer: 16x16x32 for the 16-bit igemm
+              // layers (2..13), 32x32x16 for conv1_2 (shared with the fused stage-1 kernel) and f32
+              const int c = pos ^ ((cpc == 8 && l >= 2) ? ((n >> 2) & 1) * 2 : (n >> 2) & 3);
               const size_t e0 = (((((size_t)ct * ncc + cc) * 9 + t) * bn + n) * 4 + pos) * cpc;
               for (int j = 0; j < cpc; ++j) {
                 const int cin = cc * kc + c * cpc + j, cout = ct * bn + n;

@@ -133,7 +133,8 @@ static const int kChnOff[NQA_NUM_TAPS] = {0, 3, 67, 195, 451, 963};
 // Packed-blob layout (bytes).  [0,256): zero page (source of out-of-image halo pixels).
 // Layer 0: float w[27][64] (k = (ky*3+kx)*3+c) then float bias[64].  Layers 1..12: tiles
 // [cout/64][cin/KC][9 taps][64 rows] of 64 bytes (chunk c of row n stored at position
-// c ^ ((n>>2)&3)), then float bias[cout].  The 64-channel granularity lets any block tile
+// c ^ ((n>>2)&3), or c ^ 2*((n>>2)&1) for the 16-bit layers 2..12 read by the 16x16x32 MFMA), then
+// float bias[cout].  The 64-channel granularity lets any block tile
 // that is a multiple of 64 channels stream whole sub-slabs.
 static constexpr size_t kZeroPage = 256;
 size_t layer_offset(int layer, int prec);

@@ -158,7 +158,18 @@ struct ConvGeom {
   static_assert(BN % 64 == 0 && W_ITEMS % THREADS == 0 && MP % TW == 0, "bad conv geometry");
 };
 
-template <typename P, int WAVES_N, int WAVES_M, int WN_T, int WM_T, int TW>
+// LDS row swizzle: chunk c of row r sits at position c ^ lds_swz(r).  The 32x32x16 MFMA reads one
+// chunk of 32 consecutive rows per instruction (rows spread by (r>>2)&3); the 16x16x32 MFMA reads
+// all four chunks of 16 consecutive rows (chunk = lane>>4), which is conflict-free from any base
+// row with 2*((r>>2)&1) (found by exhaustive search over the ds_read_b128 lane groups).
+template <bool M16>
+__host__ __device__ inline int lds_swz(int r) {
+  return M16 ? ((r >> 2) & 1) * 2 : (r >> 2) & 3;
+}
+
+// M16: 16-bit modes on v_mfma_f32_16x16x32 (the chip holds a higher clock on it than on 32x32x16
+// at equal cycles per FLOP); weights of those layers are packed with the matching swizzle.
+template <typename P, int WAVES_N, int WAVES_M, int WN_T, int WM_T, int TW, bool M16>
 __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void conv3x3_igemm_kernel(
     const typename P::T *__restrict__ in, const char *__restrict__ wpk, const float *__restrict__ bias,
     typename P::T *__restrict__ out, int H, int W, int Cin, int Cout, int tiles_x, int out_split) {
@@ -195,7 +206,7 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void conv3x3_igemm_kernel(
 #pragma unroll
   for (int r = 0; r < G::A_ROUNDS; ++r) {
     const int i = r * G::THREADS + tid;
-    const int q = i >> 2, c = (i & 3) ^ ((q >> 2) & 3);
+    const int q = i >> 2, c = (i & 3) ^ lds_swz<M16>(q);
     const int hy = q / G::HW_, hx = q - hy * G::HW_;
     const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
     const bool ok = i < G::A_ITEMS && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
@@ -269,6 +280,29 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void conv3x3_igemm_kernel(
     for (int j = 0; j < WM_T; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // M16: the wave's WN_T x WM_T tiles of 32x32 as 2WN_T x 2WM_T tiles of 16x16 (4 accumulators each);
+  // lane = (l15: row of the A fragment / column of the B fragment, c4: 16-byte k-chunk of the row)
+  const int l15 = lane & 15, c4 = lane >> 4;
+  int w16_addr[2 * WN_T], q16[2 * WM_T];
+  f32x4 acc16[2 * WN_T][2 * WM_T];
+  if constexpr (M16) {
+#pragma unroll
+    for (int i = 0; i < 2 * WN_T; ++i) {
+      const int cib = wn * WN_T * 32 + i * 16 + l15;
+      const int r64 = cib & 63;
+      w16_addr[i] = 2 * G::A_BYTES + (cib >> 6) * (G::SUB_STAGE_ITEMS * 16) + r64 * 64 + ((c4 ^ lds_swz<true>(r64)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 2 * WM_T; ++j) {
+      const int m = wm * WM_T * 32 + j * 16 + l15;
+      const int ty = m / TW, tx = m - ty * TW;
+      q16[j] = ty * G::HW_ + tx;
+    }
+#pragma unroll
+    for (int i = 0; i < 2 * WN_T; ++i)
+#pragma unroll
+      for (int j = 0; j < 2 * WM_T; ++j) acc16[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
 
 #ifdef NQA_STAMPS
   unsigned long long seg_sum[4] = {0, 0, 0, 0};
@@ -314,7 +348,48 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void conv3x3_igemm_kernel(
       for (int j = 0; j < WM_T; ++j) asm volatile("" ::"v"(bf[j]));
 #endif
     };
-    if constexpr (P::SPLIT) {
+    if constexpr (M16) {
+      // three k-steps per stage (one tap = the whole 64-byte row = K 32), each in two halves of the
+      // wave's channel rows: step t = (kx, half) reads WN_T weight fragments, and at half 0 the
+      // 2*WM_T pixel fragments of the tap, one step ahead of the MFMAs that use them.
+      u32x4 af[2][WN_T], bf[2][2 * WM_T];
+      auto load16 = [&](int t) {
+        const int kx = t >> 1, half = t & 1;
+#pragma unroll
+        for (int i = 0; i < WN_T; ++i)
+          af[t & 1][i] = *reinterpret_cast<const u32x4 *>(wbuf + w16_addr[half * WN_T + i] + kx * 4096);
+        if (half == 0) {
+#pragma unroll
+          for (int j = 0; j < 2 * WM_T; ++j) {
+            const int q = q16[j] + ky * G::HW_ + kx;
+            bf[kx & 1][j] = *reinterpret_cast<const u32x4 *>(abuf + q * 64 + ((c4 ^ lds_swz<true>(q)) << 4));
+          }
+        }
+      };
+      auto mma16 = [&](int t) {
+        const int kx = t >> 1, half = t & 1;
+#pragma unroll
+        for (int i = 0; i < WN_T; ++i)
+#pragma unroll
+          for (int j = 0; j < 2 * WM_T; ++j) {
+            f32x4 &c = acc16[half * WN_T + i][j];
+            if constexpr (P::ID == NQA_PREC_BF16)
+              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[t & 1][i]),
+                                                          __builtin_bit_cast(bf16x8, bf[kx & 1][j]), c, 0, 0, 0);
+            else
+              c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af[t & 1][i]),
+                                                         __builtin_bit_cast(f16x8, bf[kx & 1][j]), c, 0, 0, 0);
+          }
+      };
+      load16(0);
+#pragma unroll
+      for (int t = 0; t < 6; ++t) {
+        if (t + 1 < 6) load16(t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma16(t);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else if constexpr (P::SPLIT) {
       // split-f16 products: weight rows and pixel rows are both 16 channels as
       // [hi 0-7 | hi 8-15 | lo 0-7 | lo 8-15] halves.  One k-step per tap: lane half h contracts
       // channels 8h..8h+7 (chunk h = hi, chunk 2+h = lo), three MFMAs per tile, taken term by term
@@ -397,42 +472,51 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void conv3x3_igemm_kernel(
   static_assert(ROWS * RB <= G::LDS_BYTES, "epilogue tile does not fit the stage buffers");
   char *const obase = reinterpret_cast<char *>(out) + (size_t)ct * RB;
   const size_t rec = (size_t)Cout * sizeof(T);
+  // one lane's piece: 4 consecutive channels (first = cl, block-local) of the pixel staged in `row`
+  auto stage_piece = [&](int row, int cl, float a0, float a1, float a2, float a3) {
+    char *const rbase = smem + row * RB;
+    const int sw = row & SWZ;
+    const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bias + ct * G::BN + cl);
+    const float v[4] = {fmaxf(a0 + b4[0], 0.f), fmaxf(a1 + b4[1], 0.f), fmaxf(a2 + b4[2], 0.f),
+                        fmaxf(a3 + b4[3], 0.f)};
+    if constexpr (sizeof(T) == 4) {
+      if (P::SPLIT && out_split) {  // feeds another conv: split16 record (wave-uniform branch)
+        typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+        const h4 hi = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+        const h4 lo = {(_Float16)(v[0] - (float)hi[0]), (_Float16)(v[1] - (float)hi[1]),
+                       (_Float16)(v[2] - (float)hi[2]), (_Float16)(v[3] - (float)hi[3])};
+        const int off = (cl >> 4) * 64 + ((cl >> 3) & 1) * 16 + (cl & 7) * 2;
+        *reinterpret_cast<h4 *>(rbase + ((((off >> 4)) ^ sw) << 4) + (off & 15)) = hi;
+        *reinterpret_cast<h4 *>(rbase + ((((off >> 4) + 2) ^ sw) << 4) + (off & 15)) = lo;
+      } else {
+        const f32x4 s4 = {v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4 *>(rbase + (((cl >> 2) ^ sw) << 4)) = s4;
+      }
+    } else {
+      typedef __attribute__((ext_vector_type(4))) T t4;
+      const t4 s4 = {P::from_f(v[0]), P::from_f(v[1]), P::from_f(v[2]), P::from_f(v[3])};
+      *reinterpret_cast<t4 *>(rbase + (((cl >> 3) ^ sw) << 4) + (cl & 4) * 2) = s4;
+    }
+  };
 #pragma unroll
   for (int j = 0; j < WM_T; ++j) {
     __syncthreads();  // the last stage's LDS reads (or the previous pass's copy-out) are done
-    {
-      const int row = wm * 32 + l31;
-      char *const rbase = smem + row * RB;
-      const int sw = row & SWZ;
+    if constexpr (M16) {
+      // acc16[i][jj][e]: channel = 16*i + 4*c4 + e of the wave's rows, pixel = l15 of 16-pixel tile jj
 #pragma unroll
-      for (int i = 0; i < WN_T; ++i) {
+      for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int cl = (wn * WN_T + i) * 32 + 8 * g + 4 * h;  // first of this lane's 4 channels, block-local
-          const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bias + ct * G::BN + cl);
-          float v[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[i][j][4 * g + e] + b4[e], 0.f);
-          if constexpr (sizeof(T) == 4) {
-            if (P::SPLIT && out_split) {  // feeds another conv: split16 record (wave-uniform branch)
-              typedef __attribute__((ext_vector_type(4))) _Float16 h4;
-              const h4 hi = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-              const h4 lo = {(_Float16)(v[0] - (float)hi[0]), (_Float16)(v[1] - (float)hi[1]),
-                             (_Float16)(v[2] - (float)hi[2]), (_Float16)(v[3] - (float)hi[3])};
-              const int off = (cl >> 4) * 64 + ((cl >> 3) & 1) * 16 + (cl & 7) * 2;
-              *reinterpret_cast<h4 *>(rbase + ((((off >> 4)) ^ sw) << 4) + (off & 15)) = hi;
-              *reinterpret_cast<h4 *>(rbase + ((((off >> 4) + 2) ^ sw) << 4) + (off & 15)) = lo;
-            } else {
-              const f32x4 s4 = {v[0], v[1], v[2], v[3]};
-              *reinterpret_cast<f32x4 *>(rbase + (((cl >> 2) ^ sw) << 4)) = s4;
-            }
-          } else {
-            typedef __attribute__((ext_vector_type(4))) T t4;
-            const t4 s4 = {P::from_f(v[0]), P::from_f(v[1]), P::from_f(v[2]), P::from_f(v[3])};
-            *reinterpret_cast<t4 *>(rbase + (((cl >> 3) ^ sw) << 4) + (cl & 4) * 2) = s4;
-          }
+        for (int i = 0; i < 2 * WN_T; ++i) {
+          const f32x4 &c = acc16[i][2 * j + jj];
+          stage_piece(wm * 32 + jj * 16 + l15, wn * WN_T * 32 + i * 16 + 4 * c4, c[0], c[1], c[2], c[3]);
         }
-      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < WN_T; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          stage_piece(wm * 32 + l31, (wn * WN_T + i) * 32 + 8 * g + 4 * h, acc[i][j][4 * g], acc[i][j][4 * g + 1],
+                      acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
     }
     __syncthreads();
 #pragma unroll 2
@@ -764,13 +848,13 @@ static int launch_conv1_1(const float *x, int n, int H, int W, const char *packe
   return check_launch("conv1_1");
 }
 
-template <typename P, int WAVES_N, int WAVES_M, int WN_T, int WM_T, int TW>
+template <typename P, int WAVES_N, int WAVES_M, int WN_T, int WM_T, int TW, bool M16 = (sizeof(typename P::T) == 2)>
 static int launch_igemm(const void *in, int n, int H, int W, int cin, int cout, const char *wpk, const float *bias,
                         void *out, int out_split, hipStream_t st) {
   typedef ConvGeom<WAVES_N, WAVES_M, WN_T, WM_T, TW> G;
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_igemm_kernel<P, WAVES_N, WAVES_M, WN_T, WM_T, TW>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_igemm_kernel<P, WAVES_N, WAVES_M, WN_T, WM_T, TW, M16>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES) != hipSuccess) {
       set_error("conv3x3_igemm: cannot raise the dynamic LDS limit to %d bytes", G::LDS_BYTES);
       return NQA_E_LAUNCH;
@@ -780,7 +864,7 @@ static int launch_igemm(const void *in, int n, int H, int W, int cin, int cout, 
   const int tiles_x = cdiv(W, TW), tiles_y = cdiv(H, G::TH);
   dim3 grid(tiles_x * tiles_y, n, cout / G::BN);
   TimedLaunch t(NQA_K_CONV, st);
-  conv3x3_igemm_kernel<P, WAVES_N, WAVES_M, WN_T, WM_T, TW><<<grid, G::THREADS, G::LDS_BYTES, st>>>(
+  conv3x3_igemm_kernel<P, WAVES_N, WAVES_M, WN_T, WM_T, TW, M16><<<grid, G::THREADS, G::LDS_BYTES, st>>>(
       reinterpret_cast<const typename P::T *>(in), wpk, bias, reinterpret_cast<typename P::T *>(out), H, W, cin, cout,
       tiles_x, out_split);
   return check_launch("conv3x3_igemm");
@@ -815,7 +899,10 @@ static int launch_conv(const void *in, int n, int H, int W, int layer, const cha
 #define NQA_GO(WN, WM, TN, TM)                                                                                      \
   return narrow ? launch_igemm<P, WN, WM, TN, TM, 16>(in, n, H, W, cs.cin, cs.cout, wpk, bias, out, out_split, st) \
                 : launch_igemm<P, WN, WM, TN, TM, 32>(in, n, H, W, cs.cin, cs.cout, wpk, bias, out, out_split, st)
-  if (cs.cout == 64) { NQA_GO(1, 4, 2, 2); }                    // 64 ch x 256 px, 4 waves
+  if (cs.cout == 64) {  // 64 ch x 256 px, 4 waves; 32x32x16 MFMA: its packed weights are shared with conv1_fused
+    return narrow ? launch_igemm<P, 1, 4, 2, 2, 16, false>(in, n, H, W, cs.cin, cs.cout, wpk, bias, out, out_split, st)
+                  : launch_igemm<P, 1, 4, 2, 2, 32, false>(in, n, H, W, cs.cin, cs.cout, wpk, bias, out, out_split, st);
+  }
   if constexpr (!P::SPLIT) {
     if (wide) return launch_igemm<P, 2, 4, 2, 4, 32>(in, n, H, W, cs.cin, cs.cout, wpk, bias, out, out_split, st);
   }

@@ -34,8 +34,9 @@ def test_argument_errors(lib):
     assert lib.nqa_workspace_bytes(0, 8, 8, 0) == 0
 
 
-def _unpack_layer(blob, off, cin, cout, dtype, cpc):
-    """Invert the documented tile layout back to OIHW (numpy)."""
+def _unpack_layer(blob, off, cin, cout, dtype, cpc, m16=False):
+    """Invert the documented tile layout back to OIHW (numpy).  m16: the chunk swizzle of the 16x16x32-MFMA
+    layers (16-bit modes, layers 2..13): 2*((n>>2)&1) instead of (n>>2)&3."""
     kc, bn = 4 * cpc, 64
     ncc = cin // kc
     n_el = cin * cout * 9
@@ -43,7 +44,7 @@ def _unpack_layer(blob, off, cin, cout, dtype, cpc):
     w = np.zeros((cout, cin, 9), dtype=dtype)
     for n in range(bn):
         for pos in range(4):
-            c = pos ^ ((n >> 2) & 3)
+            c = pos ^ (((n >> 2) & 1) * 2 if m16 else (n >> 2) & 3)
             # raw[ct, cc, t, n, pos, j] -> w[ct*bn+n, cc*kc + c*cpc + j, t]
             src = raw[:, :, :, n, pos, :]  # (ct, cc, t, j)
             for ct in range(cout // bn):
@@ -84,10 +85,10 @@ def test_pack_roundtrip(prec, np_convs, lib):
             got = _unpack_layer(blob, o, cin, cout, np.float32, 4)
             assert np.array_equal(got, w)
         elif prec == "f16":
-            got = _unpack_layer(blob, o, cin, cout, np.float16, 8)
+            got = _unpack_layer(blob, o, cin, cout, np.float16, 8, m16=l >= 2)
             assert np.array_equal(got, w.astype(np.float16))
         else:
-            got = _unpack_layer(blob, o, cin, cout, np.uint16, 8)
+            got = _unpack_layer(blob, o, cin, cout, np.uint16, 8, m16=l >= 2)
             ref = torch.from_numpy(w).to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)
             assert np.array_equal(got, ref)
         bias = blob[o + al(cin * cout * 9 * esz):][:cout * 4].view(np.float32)
