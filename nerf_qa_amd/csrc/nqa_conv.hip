@@ -835,7 +835,7 @@ extern "C" int nqa_debug_stamps(unsigned long long *out8, int reset) {
 }
 #endif
 
-static int g_conv_variant = 2;  // 0: 4-wave tiles everywhere; 1: + 8-wave 256x256 tiles; 2: + 8-wave 128x512 tiles
+static int g_conv_variant = 1;  // 0: 4-wave tiles everywhere; 1: + 8-wave 256x256 tiles; 2: + 8-wave 128x512 tiles
 void set_conv_variant(int v) { g_conv_variant = v; }
 
 template <typename P>

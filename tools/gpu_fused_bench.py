@@ -24,3 +24,15 @@ for (H, W, N) in ((256, 256, 64), (1080, 1920, 8)):
     e1.record()
     torch.cuda.synchronize()
     print(f"{H}x{W} N={N}: {e0.elapsed_time(e1) / 10 * 1e3:.1f} us")
+    # the unfused alternative: conv1_1 (f16 NHWC out) + conv1_2 on the implicit-GEMM kernel
+    a = ops.conv1_1(x, packed, "f16")
+    for fn, name in ((lambda: ops.conv1_1(x, packed, "f16"), "conv1_1"), (lambda: ops.conv3x3_relu(a, 1, packed, "f16"), "conv1_2 igemm")):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(10):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        print(f"   {name}: {e0.elapsed_time(e1) / 10 * 1e3:.1f} us")

@@ -14,7 +14,7 @@ def short(name):
     return name.replace("void nqa::", "").replace("nqa::", "").split("(")[0][:70]
 
 
-for tag in ("trace256", "trace1080"):
+for tag in ("trace256", "trace1080", "traceadists"):
     fs = glob.glob(f"{src}/{tag}/*/*_kernel_stats.csv")
     if not fs:
         continue
