@@ -29,6 +29,10 @@ def _need_cuda(*ts: torch.Tensor) -> torch.device:
                                 "(move inputs and the module to cuda; there is no CPU fallback)" % t.device)
         if t.device != dev:
             raise _lib.NqaError("tensors on different devices")
+    # the library launches on the current HIP device; make that the tensors' device (a process that
+    # drives several GPUs from one thread would otherwise launch on the wrong one and fault)
+    if dev.index is not None and dev.index != torch.cuda.current_device():
+        torch.cuda.set_device(dev)
     return dev
 
 
