@@ -21,8 +21,6 @@
 namespace nqa {
 
 static constexpr int kWin = 21;
-static constexpr int kTile = 16;            // output tile edge
-static constexpr int kHalo = kTile + kWin - 1;  // 36
 
 struct Gauss {
   float g[kWin];
@@ -195,113 +193,6 @@ __global__ __launch_bounds__(256) void adists_weights_kernel(const float *__rest
 }
 
 // ---------------------------------------------------------------------------------
-// The windowed pass of one stage.  Block = 16x16 output pixels of image pair b; loop over
-// channel quads: stage a 36x36 halo of x and y (fp32) in LDS, 21-tap horizontal pass of the
-// five products into LDS, 21-tap vertical pass per output pixel, then T/S/gamma per channel.
-template <typename P>
-__global__ __launch_bounds__(256) void adists_window_kernel(const typename P::T *__restrict__ fx,
-                                                            const typename P::T *__restrict__ fy, int H, int W, int C,
-                                                            int creal, const float *__restrict__ q, int B, int ctot,
-                                                            int coff, const float *__restrict__ wgt, Gauss gw,
-                                                            float *__restrict__ gamma, float *__restrict__ tw,
-                                                            float *__restrict__ sw) {
-  typedef typename P::T T;
-  typedef __attribute__((ext_vector_type(4))) T t4;
-  extern __shared__ __attribute__((aligned(16))) char dyn[];
-  f32x4 *sx = reinterpret_cast<f32x4 *>(dyn);                 // [36][36]
-  f32x4 *sy = sx + kHalo * kHalo;                              // [36][36]
-  f32x4 *hb = sy + kHalo * kHalo;                              // [5][36][16]
-  const int tid = threadIdx.x, b = blockIdx.z;
-  const int ox0 = blockIdx.x * kTile, oy0 = blockIdx.y * kTile;
-  const int Ho = H - (kWin - 1), Wo = W - (kWin - 1);
-  const int ty = tid >> 4, tx = tid & 15;
-  const T *px = fx + (size_t)b * H * W * C;
-  const T *py = fy + (size_t)b * H * W * C;
-  const size_t st = (size_t)B * ctot, qo = (size_t)b * ctot + coff;
-  float g_acc = 0.f, t_acc = 0.f, s_acc = 0.f;
-  for (int c0 = 0; c0 < C; c0 += 4) {
-    __syncthreads();
-    for (int i = tid; i < kHalo * kHalo; i += 256) {
-      const int r = i / kHalo, cc = i - r * kHalo;
-      const int gy = oy0 + r, gx = ox0 + cc;
-      f32x4 vx = {0.f, 0.f, 0.f, 0.f}, vy = vx;
-      if (gy < H && gx < W) {
-        const size_t o = ((size_t)gy * W + gx) * C + c0;
-        const t4 ax = *reinterpret_cast<const t4 *>(px + o), ay = *reinterpret_cast<const t4 *>(py + o);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          vx[e] = P::to_f(ax[e]);
-          vy[e] = P::to_f(ay[e]);
-        }
-      }
-      sx[i] = vx;
-      sy[i] = vy;
-    }
-    __syncthreads();
-    for (int i = tid; i < kHalo * kTile; i += 256) {
-      const int r = i >> 4, cc = i & 15;
-      f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0, a4 = a0;
-#pragma unroll
-      for (int k = 0; k < kWin; ++k) {
-        const f32x4 vx = sx[r * kHalo + cc + k], vy = sy[r * kHalo + cc + k];
-        const float g = gw.g[k];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float gx_ = g * vx[e], gy_ = g * vy[e];
-          a0[e] += gx_;
-          a1[e] += gy_;
-          a2[e] = fmaf(gx_, vx[e], a2[e]);
-          a3[e] = fmaf(gy_, vy[e], a3[e]);
-          a4[e] = fmaf(gx_, vy[e], a4[e]);
-        }
-      }
-      hb[0 * kHalo * kTile + i] = a0;
-      hb[1 * kHalo * kTile + i] = a1;
-      hb[2 * kHalo * kTile + i] = a2;
-      hb[3 * kHalo * kTile + i] = a3;
-      hb[4 * kHalo * kTile + i] = a4;
-    }
-    __syncthreads();
-    f32x4 m[5];
-#pragma unroll
-    for (int j = 0; j < 5; ++j) m[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < kWin; ++k) {
-      const float g = gw.g[k];
-#pragma unroll
-      for (int j = 0; j < 5; ++j) {
-        const f32x4 v = hb[j * kHalo * kTile + (ty + k) * kTile + tx];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) m[j][e] = fmaf(g, v[e], m[j][e]);
-      }
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int c = c0 + e;
-      if (c < creal) {
-        const float ix = q[0 * st + qo + c], iy = q[1 * st + qo + c], w = wgt[qo + c];
-        const float rmx = m[0][e], rex2 = m[2][e];
-        g_acc += (rex2 - rmx * rmx) / (rmx + 1e-12f);
-        const float mx = ix * rmx, my = iy * m[1][e];
-        const float vx = ix * ix * rex2 - mx * mx, vy = iy * iy * m[3][e] - my * my;
-        const float cov = ix * iy * m[4][e] - mx * my;
-        const float t = (2.f * mx * my + 1e-6f) / (mx * mx + my * my + 1e-6f);
-        const float s = (2.f * cov + 1e-6f) / (vx + vy + 1e-6f);
-        t_acc = fmaf(w, t, t_acc);
-        s_acc = fmaf(w, s, s_acc);
-      }
-    }
-  }
-  const int oy = oy0 + ty, ox = ox0 + tx;
-  if (oy < Ho && ox < Wo) {
-    const size_t o = ((size_t)b * Ho + oy) * Wo + ox;
-    gamma[o] = g_acc / (float)creal;
-    tw[o] = t_acc;
-    sw[o] = s_acc;
-  }
-}
-
-// ---------------------------------------------------------------------------------
 // The windowed pass for the NHWC taps (stages 1..5), lanes = channels.
 //
 // A wave owns one output column x of image pair b and a strip of up to 64 output rows, and walks
@@ -445,6 +336,114 @@ __global__ __launch_bounds__(256, 2) void adists_window_lanes_kernel(
     gamma[o] = acc_g / (float)C;
     tw[o] = acc_t;
     sw[o] = acc_s;
+  }
+}
+
+// The windowed pass of stage 0 (the raw image: 3 float planes, NCHW) in the same shape as the lanes
+// kernel above, with lanes = 64 adjacent output COLUMNS of one plane: every tap load is a coalesced
+// row segment at an immediate offset from one row pointer, the ring and the packed tap arithmetic
+// are identical, nothing is reduced across lanes, and the three channels are accumulated into the
+// maps one after the other by the same lane (plain read-modify-write, no atomics).
+__global__ __launch_bounds__(256, 2) void adists_window_planar_kernel(
+    const float *__restrict__ x, const float *__restrict__ y, int H, int W, const float *__restrict__ q, int B,
+    int ctot, int coff, const float *__restrict__ wgt, Gauss gw, const float *__restrict__ g2,
+    float *__restrict__ gamma, float *__restrict__ tw, float *__restrict__ sw) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.z;
+  const int Ho = H - (kWin - 1), Wo = W - (kWin - 1);
+  const int ox0 = blockIdx.x * 256 + wave * 64;
+  if (ox0 >= Wo) return;
+  const int ox = ox0 + lane;
+  const bool live = ox < Wo;
+  const int oxc = live ? ox : Wo - 1;  // dead lanes re-read the last column and store nothing
+  const int oy0 = blockIdx.y * 64;
+  const int nout = min(64, Ho - oy0);
+  const int nrows = nout + kWin - 1;
+  const size_t st = (size_t)B * ctot, qo = (size_t)b * ctot + coff;
+  const size_t o0 = ((size_t)b * Ho + oy0) * Wo + ox;
+  for (int c = 0; c < 3; ++c) {
+    const float ix = q[0 * st + qo + c], iy = q[1 * st + qo + c], wc = wgt[qo + c];
+    const float *px = x + ((size_t)(b * 3 + c) * H + oy0) * W + oxc;
+    const float *py = y + ((size_t)(b * 3 + c) * H + oy0) * W + oxc;
+    f32x2 r01[3][7], r23[3][7];
+    float r4[3][7];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int u = 0; u < 7; ++u) {
+        r01[g][u] = r23[g][u] = (f32x2){0.f, 0.f};
+        r4[g][u] = 0.f;
+      }
+    int grp = 0;
+    for (int rr0 = 0; rr0 < nrows; rr0 += 7) {
+#pragma unroll
+      for (int sub = 0; sub < 7; ++sub) {
+        const int rr = rr0 + sub;
+        if (rr < nrows) {
+          float xr[kWin], yr[kWin];
+#pragma unroll
+          for (int j = 0; j < kWin; ++j) {
+            xr[j] = px[j];
+            yr[j] = py[j];
+          }
+          px += W;
+          py += W;
+          __builtin_amdgcn_sched_barrier(0);
+          f32x2 h01 = {0.f, 0.f}, h23 = {0.f, 0.f};
+          float h4 = 0.f;
+#pragma unroll
+          for (int j = 0; j < kWin; ++j) {
+            const f32x2 v = {xr[j], yr[j]};
+            const f32x2 gv = gw.g[j] * v;
+            h01 += gv;
+            h23 = gv * v + h23;
+            h4 = fmaf(gv[0], v[1], h4);
+          }
+#pragma unroll
+          for (int g = 0; g < 3; ++g) {
+            const bool hit = grp == g;
+            r01[g][sub] = hit ? h01 : r01[g][sub];
+            r23[g][sub] = hit ? h23 : r23[g][sub];
+            r4[g][sub] = hit ? h4 : r4[g][sub];
+          }
+          if (rr >= kWin - 1) {
+            const float *gv = g2 + (kWin - 1 - (grp * 7 + sub));
+            f32x2 m01 = {0.f, 0.f}, m23 = {0.f, 0.f};
+            float m4 = 0.f;
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+              for (int u = 0; u < 7; ++u) {
+                const float wv = gv[g * 7 + u];
+                m01 = wv * r01[g][u] + m01;
+                m23 = wv * r23[g][u] + m23;
+                m4 = fmaf(wv, r4[g][u], m4);
+              }
+            const float m0 = m01[0], m1 = m01[1], m2 = m23[0], m3 = m23[1];
+            const float gterm = (m2 - m0 * m0) / (m0 + 1e-12f);
+            const float mx = ix * m0, my = iy * m1;
+            const float vx = ix * ix * m2 - mx * mx, vy = iy * iy * m3 - my * my;
+            const float cov = ix * iy * m4 - mx * my;
+            const float tt = wc * ((2.f * mx * my + 1e-6f) / (mx * mx + my * my + 1e-6f));
+            const float ss = wc * ((2.f * cov + 1e-6f) / (vx + vy + 1e-6f));
+            if (live) {
+              const size_t o = o0 + (size_t)(rr - (kWin - 1)) * Wo;
+              if (c == 0) {
+                gamma[o] = gterm;
+                tw[o] = tt;
+                sw[o] = ss;
+              } else {
+                const float gsum = gamma[o] + gterm;
+                gamma[o] = c == 2 ? gsum / 3.f : gsum;
+                tw[o] += tt;
+                sw[o] += ss;
+              }
+            }
+          }
+        }
+      }
+      grp = grp == 2 ? 0 : grp + 1;
+    }
   }
 }
 
@@ -819,27 +818,14 @@ static int launch_entropy(const void *feat, int B, int HW, int C, int ppb, const
   return check_launch("entropy");
 }
 
-template <typename P>
-static int launch_window(const void *fx, const void *fy, int B, int H, int W, int C, int creal, const float *q,
-                         int ctot, int coff, const float *wgt, const Gauss &g, float *gamma, float *tw, float *sw,
-                         hipStream_t st) {
+static int launch_window_planar(const float *x, const float *y, int B, int H, int W, const float *q, int ctot, int coff,
+                                const float *wgt, const Gauss &g, const float *g2, float *gamma, float *tw, float *sw,
+                                hipStream_t st) {
   const int Ho = H - (kWin - 1), Wo = W - (kWin - 1);
-  dim3 grid(cdiv(Wo, kTile), cdiv(Ho, kTile), B);
-  const size_t lds = (size_t)(2 * kHalo * kHalo + 5 * kHalo * kTile) * 16;  // 87.5 KB of the CU's 160 KB
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(adists_window_kernel<P>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-      set_error("adists_window: cannot raise the dynamic LDS limit to %zu bytes", lds);
-      return NQA_E_LAUNCH;
-    }
-    attr_done = true;
-  }
+  dim3 grid(cdiv(Wo, 256), cdiv(Ho, 64), B);
   TimedLaunch t(NQA_K_ADISTS, st);
-  adists_window_kernel<P><<<grid, 256, lds, st>>>(reinterpret_cast<const typename P::T *>(fx),
-                                                  reinterpret_cast<const typename P::T *>(fy), H, W, C, creal, q, B,
-                                                  ctot, coff, wgt, g, gamma, tw, sw);
-  return check_launch("adists_window");
+  adists_window_planar_kernel<<<grid, 256, 0, st>>>(x, y, H, W, q, B, ctot, coff, wgt, g, g2, gamma, tw, sw);
+  return check_launch("adists_window_planar");
 }
 
 template <typename P>
@@ -994,7 +980,7 @@ static int adists_run(const float *x, const float *y, int B, int H, int W, const
       continue;
     }
     if (k == 0) {
-      rc = launch_window<PrecF32>(img4x, img4y, B, H, W, 4, 3, q, ctot, 0, wgt, gauss, gamma, tw, sw, st);
+      rc = launch_window_planar(x, y, B, H, W, q, ctot, 0, wgt, gauss, g2, gamma, tw, sw, st);
     } else {
       const char *tx = static_cast<const char *>(taps[k - 1]);
       const char *ty = tx + (size_t)B * p.h[k] * p.w[k] * p.c[k] * esz;
