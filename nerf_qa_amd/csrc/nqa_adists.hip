@@ -229,9 +229,9 @@ __device__ inline float wave_sum(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
-template <typename P>
+template <typename P, int C>  // C (64..512) is a template parameter so tap strides fold into load immediates
 __global__ __launch_bounds__(256, 2) void adists_window_lanes_kernel(
-    const typename P::T *__restrict__ fx, const typename P::T *__restrict__ fy, int H, int W, int C,
+    const typename P::T *__restrict__ fx, const typename P::T *__restrict__ fy, int H, int W,
     const float *__restrict__ q, int B, int ctot, int coff, const float *__restrict__ wgt, Gauss gw,
     const float *__restrict__ g2, float *__restrict__ gamma, float *__restrict__ tw, float *__restrict__ sw) {
   typedef typename P::T T;
@@ -835,9 +835,14 @@ static int launch_window_lanes(const void *fx, const void *fy, int B, int H, int
   const int Ho = H - (kWin - 1), Wo = W - (kWin - 1);
   dim3 grid(cdiv(Wo, 4), cdiv(Ho, 64), B);
   TimedLaunch t(NQA_K_ADISTS, st);
-  adists_window_lanes_kernel<P><<<grid, 256, 0, st>>>(reinterpret_cast<const typename P::T *>(fx),
-                                                      reinterpret_cast<const typename P::T *>(fy), H, W, C, q, B, ctot,
-                                                      coff, wgt, g, g2, gamma, tw, sw);
+  const typename P::T *px = reinterpret_cast<const typename P::T *>(fx), *py = reinterpret_cast<const typename P::T *>(fy);
+  switch (C) {
+    case 64: adists_window_lanes_kernel<P, 64><<<grid, 256, 0, st>>>(px, py, H, W, q, B, ctot, coff, wgt, g, g2, gamma, tw, sw); break;
+    case 128: adists_window_lanes_kernel<P, 128><<<grid, 256, 0, st>>>(px, py, H, W, q, B, ctot, coff, wgt, g, g2, gamma, tw, sw); break;
+    case 256: adists_window_lanes_kernel<P, 256><<<grid, 256, 0, st>>>(px, py, H, W, q, B, ctot, coff, wgt, g, g2, gamma, tw, sw); break;
+    case 512: adists_window_lanes_kernel<P, 512><<<grid, 256, 0, st>>>(px, py, H, W, q, B, ctot, coff, wgt, g, g2, gamma, tw, sw); break;
+    default: set_error("adists_window_lanes: unsupported channel count %d", C); return NQA_E_SHAPE;
+  }
   return check_launch("adists_window_lanes");
 }
 
