@@ -67,14 +67,20 @@ __global__ __launch_bounds__(256) void conv1_1_kernel(const float *__restrict__ 
 #pragma unroll 1
     for (int g = 0; g < HC / 16; ++g) {
       const int c0 = half * HC + g * 16;
-      float acc[16];
+      // channel pairs as packed floats: v_pk_fma_f32 with the two weights as one scalar pair
+      typedef __attribute__((ext_vector_type(2))) float f32x2;
+      f32x2 acc2[8];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) acc[j] = bias[c0 + j];
+      for (int j = 0; j < 8; ++j) acc2[j] = *reinterpret_cast<const f32x2 *>(bias + c0 + 2 * j);
 #pragma unroll
       for (int k = 0; k < 27; ++k) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) acc[j] = fmaf(in[k], w[k * 64 + c0 + j], acc[j]);
+        for (int j = 0; j < 8; ++j)
+          acc2[j] = in[k] * *reinterpret_cast<const f32x2 *>(w + k * 64 + c0 + 2 * j) + acc2[j];
       }
+      float acc[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[j] = acc2[j >> 1][j & 1];
       T *row = reinterpret_cast<T *>(tile + tid * PITCH) + g * 16;
       if constexpr (P::SPLIT) {  // one split16 record (64 B) per 16 channels, same bytes per pass as float
 #pragma unroll
