@@ -416,14 +416,24 @@ int stats_nhwc(const void *feat, int B, int HW, int C, int prec, double *part, h
   return NQA_E_ARG;
 }
 
-// Tile shape of the fused pool+statistics pass for an Ho x Wo pooled map: up to 8 rows tall,
-// units_per_block pixels in all; returns the number of tiles (= blocks per image pair).
+// Tile shape of the fused pool+statistics pass for an Ho x Wo pooled map: units_per_block pooled
+// pixels as a NARROW, TALL tile.  Every odd input row serves two pooled rows; a block walks its
+// tile row by row, so with a narrow tile the second use follows the first within a pass or two and
+// hits L1/L2.  (With wide 8-row tiles the row had left the XCD's 4 MB L2 by then: rocprof FETCH_SIZE
+// read 1.5x the algorithmic bytes on every tap.)  The width keeps one input row of the tile near
+// 8 KB and is a multiple of the pixels the block covers per pass.
 int pool_stats_tiles(int Ho, int Wo, int C, int prec, int B, int *tr, int *tc) {
   prec = storage_prec(prec);
   const int upb = stats_units_per_block(Ho * Wo, C, prec, B);
-  int TR = 8;
-  while (TR > 1 && (upb % TR || upb / TR < 4 || TR > Ho)) TR >>= 1;
-  const int TC = upb / TR;
+  const int esz = (int)prec_elem_bytes(prec), cpc = 16 / esz;
+  const int PL = 256 / (C / cpc);  // pooled pixels per pass of the block
+  int TC = 8192 / (C * esz);
+  TC = TC > 32 ? 32 : TC;
+  TC = TC < PL ? PL : TC / PL * PL;
+  if (TC > Wo) TC = cdiv(Wo, PL) * PL;
+  int TR = upb / TC;
+  if (TR < 1) TR = 1;
+  if (TR > Ho) TR = Ho;
   if (tr) *tr = TR;
   if (tc) *tc = TC;
   return cdiv(Wo, TC) * cdiv(Ho, TR);

@@ -53,7 +53,7 @@ with open(f"{dst}/hbm_traffic_1080p.csv", "w") as f:
         fe = 2 * tr[k]["FETCH_SIZE"] * 1024 / n / 1e6
         wr = tr[k]["WRITE_SIZE"] * 1024 / max(cnt[k]["WRITE_SIZE"], 1) / 1e6
         us = dur[k] / n
-        f.write(f"\"{k}\",{n},{fe:.1f},{wr:.1f},{us:.1f},{(fe + wr) / max(us, 1e-9) * 1e3 / 1e3:.0f}\n")
+        f.write(f"\"{k}\",{n},{fe:.1f},{wr:.1f},{us:.1f},{(fe + wr) / max(us, 1e-9) * 1e3:.0f}\n")
 
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 n = collections.Counter()
