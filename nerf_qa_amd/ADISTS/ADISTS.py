@@ -10,9 +10,10 @@ only (:147,153), so callers pass x = reference frame (prep.py:186).
 Precision: the default here is "f32s": float32 activations, convolutions on the f16 matrix cores
 with both operands split into (hi, lo) half pairs (3 MFMAs per product) -- 1e-7 from the exact-f32
 path and from the reference, at ~1.9x the exact-f32 ("f32") throughput.  Plain 16-bit features are
-NOT safe for A-DISTS: it min-max-normalises a sigmoid of a z-scored variance/mean ratio (:82-90),
-and on some inputs that chain amplifies the 2^-11 rounding of f16 weights or activations to 3-5e-4
-in the score, which breaks the 1e-4 bar DISTS' smooth statistics keep with margin.
+NOT safe for A-DISTS: F.normalize (:166-167) and the entropy weights (:127-135) rescale every channel by
+its own L2 norm, so a channel that is dead except for one pixel at 1e-4 is a full-scale feature
+after normalisation, and the same channel rounded to exactly dead contributes T = S = 1 -- one such
+flip moves the score by a channel weight, ~5e-4 (measured; DISTS' statistics have no such edge).
 precision="f16" stays available as the opt-in fast mode (3x the throughput at 1080p).
 
 as_loss=True in the reference runs the pyramids WITH autograd (:139-141); this build has
