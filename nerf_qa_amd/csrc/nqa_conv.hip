@@ -892,6 +892,10 @@ static int launch_conv(const void *in, int n, int H, int W, int layer, const cha
     const double eff_big = (double)H * W / ((double)cdiv(W, 32) * cdiv(H, 8) * 256.0);
     const double eff_small = (double)H * W / ((double)cdiv(W, 32) * cdiv(H, 4) * 128.0);
     big = eff_big * 1.05 >= eff_small;
+    // small batches: a grid of 8-wave tiles that cannot give every CU a block leaves most of the chip
+    // idle for the whole layer; four times as many 4-wave tiles fill it better
+    const long blocks_big = (long)cdiv(W, 32) * cdiv(H, 8) * n * (cs.cout / 256);
+    if (blocks_big < 192) big = false;
   }
   // 8-wave 128 ch x 512 px tiles: the loop is bound by what a CU can take in per clock (weights
   // 3*BN*64 B + halo per stage), and for the same 64 K accumulators 128 x 512 moves 37.6 KB per
