@@ -1,0 +1,71 @@
+"""The VGG-16 checkpoint path: a local torchvision-format state dict replaces the stand-in weights."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+
+def _state_dict(seed):
+    from nerf_qa_amd import synth
+    sd = {}
+    for idx, (w, b) in zip(synth.VGG_FEATURE_IDX, synth.vgg16_weights(seed)):
+        sd[f"features.{idx}.weight"] = torch.from_numpy(w)
+        sd[f"features.{idx}.bias"] = torch.from_numpy(b)
+    sd["classifier.0.weight"] = torch.zeros(4, 4)  # the real checkpoint carries the classifier too
+    return sd
+
+
+def test_checkpoint_file_is_used(tmp_path, monkeypatch):
+    from nerf_qa_amd import synth
+    from nerf_qa_amd.vgg_weights import load_vgg16_convs
+    p = tmp_path / "vgg16-local.pth"
+    torch.save(_state_dict(77), p)
+    convs, tag = load_vgg16_convs(str(p))
+    assert tag == f"file:{p}" and len(convs) == 13
+    for (w, b), (rw, rb) in zip(convs, synth.vgg16_weights(77)):
+        assert np.array_equal(w.numpy(), rw) and np.array_equal(b.numpy(), rb)
+    monkeypatch.setenv("NQA_VGG16_WEIGHTS", str(p))  # the environment variable works the same way
+    convs2, tag2 = load_vgg16_convs()
+    assert tag2 == tag and torch.equal(convs2[5][0], convs[5][0])
+    torch.save({"state_dict": _state_dict(78)}, p)  # wrapped checkpoints are unwrapped
+    assert np.array_equal(load_vgg16_convs(str(p))[0][0][0].numpy(), synth.vgg16_weights(78)[0][0])
+
+
+def test_bad_checkpoint_is_refused(tmp_path):
+    from nerf_qa_amd.vgg_weights import load_vgg16_convs
+    sd = _state_dict(5)
+    sd["features.7.weight"] = torch.zeros(128, 64, 3, 3)  # wrong cin for conv2_2
+    p = tmp_path / "bad.pth"
+    torch.save(sd, p)
+    with pytest.raises(ValueError):
+        load_vgg16_convs(str(p))
+
+
+def test_stand_in_warns(monkeypatch):
+    from nerf_qa_amd.vgg_weights import load_vgg16_convs
+    monkeypatch.delenv("NQA_VGG16_WEIGHTS", raising=False)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        _, tag = load_vgg16_convs()
+    assert tag == "synth:1234" and any("stand-in" in str(r.message) for r in rec)
+
+
+@pytest.mark.gpu
+def test_module_scores_follow_the_checkpoint(tmp_path):
+    """A module built from a checkpoint file scores with THOSE weights (here: equal to the oracle run on them)."""
+    from nerf_qa_amd import synth
+    from nerf_qa_amd.DISTS_pytorch import DISTS
+    from oracle import dists_oracle
+    p = tmp_path / "vgg16-local.pth"
+    torch.save(_state_dict(99), p)
+    dev = torch.device("cuda:0")
+    m = DISTS(vgg16_path=str(p), precision="f32").to(dev).eval()
+    assert m.vgg_source == f"file:{p}"
+    xn, yn = synth.frame_batch([1, 2], 48, 64)
+    x, y = torch.from_numpy(xn), torch.from_numpy(yn)
+    ref = dists_oracle.dists(x, y, dists_oracle.convs_from_numpy(synth.vgg16_weights(99)), m.alpha.detach().cpu(),
+                             m.beta.detach().cpu())
+    with torch.no_grad():
+        got = m(x.to(dev), y.to(dev)).cpu()
+    assert (got - ref).abs().max().item() <= 5e-6
