@@ -232,7 +232,7 @@ int nqa_version(void) { return NQA_VERSION; }
 const char *nqa_last_error(void) { return g_err; }
 
 int nqa_set_conv_variant(int variant) {
-  if (variant < 0 || variant > 2) {
+  if (variant < 0 || variant > 7 || (variant & 3) == 3) {
     set_error("set_conv_variant: unknown variant %d", variant);
     return NQA_E_ARG;
   }

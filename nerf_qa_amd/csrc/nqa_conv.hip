@@ -828,6 +828,272 @@ __global__ __launch_bounds__(512) void conv1_fused_kernel(const float *__restric
 }
 
 // ---------------------------------------------------------------------------------
+// Stage 1, second form (16-bit modes): conv1_2 as an ordinary implicit-GEMM tile whose halo is not
+// loaded but COMPUTED -- the block runs conv1_1 (+ bias, ReLU, conv1_2's zero padding) for its
+// 10x34 halo patch straight into the two LDS halo buffers (64 channels = both 32-channel chunks),
+// then streams only conv1_2's weights through the usual 6-stage loop.  relu1_1 never exists in HBM
+// and nothing of the tile waits for an activation DMA; two independent blocks per CU overlap one
+// block's conv1_1 prologue (loads, VALU, LDS writes) with the other's MFMA stages.
+// conv1_1 runs on MFMA as in conv1_fused_kernel: k = ky*16 + kx*4 + c, so a lane's B fragment is
+// 16 contiguous bytes of the wave's normalised raw patch and K = 48 is three MFMAs per 32x32 tile.
+struct Conv1Tile {
+  typedef ConvGeom<1, 4, 2, 2, 32> G;  // 64 ch x 256 px (8 x 32), 4 waves, each 64 ch x 64 px
+  static constexpr int RAW_W = 40, RAW_WAVE_BYTES = 4 * RAW_W * 8;
+  static constexpr int RAW_OFF = G::LDS_BYTES;
+  static constexpr int LDS_BYTES = RAW_OFF + 4 * RAW_WAVE_BYTES;
+  static constexpr int NPT = (G::NQ + 31) / 32;  // 32-pixel column tiles of the halo patch (11)
+  static constexpr int PT_PER_WAVE = (NPT + 3) / 4;
+};
+
+template <typename P>
+__global__ __launch_bounds__(256) void conv1_tile_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                         int B, const char *__restrict__ w1m,
+                                                         const float *__restrict__ bias1,
+                                                         const char *__restrict__ w2pk,
+                                                         const float *__restrict__ bias2,
+                                                         typename P::T *__restrict__ out, int H, int W, int tiles_x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef typename P::T T;
+  typedef Conv1Tile F;
+  typedef F::G G;
+  constexpr int WN_T = 2, WM_T = 2, TW = 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [A0][A1][W0][W1][raw x4]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, h = lane >> 5;
+  const int HW = H * W;
+  int tile_id = blockIdx.x;
+  {
+    const int nb = gridDim.x, qq = nb >> 3, rr = nb & 7, xcd = tile_id & 7, local = tile_id >> 3;
+    tile_id = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + local;
+  }
+  const int bx = tile_id % tiles_x, by = tile_id / tiles_x;
+  const int n = blockIdx.y;
+  const int x0 = bx * TW, y0 = by * G::TH;
+  const int wm = wave;
+  constexpr int S = 6;  // 2 chunks of 32 channels x 3 kernel rows
+
+  // ---- weights of conv1_2: LDS-DMA, one kernel row of one chunk per stage ----
+  const __amdgpu_buffer_rsrc_t w_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(w2pk), 0, 2 * 9 * 64 * 64, 0x00020000);
+  unsigned w_goff[G::W_ROUNDS];
+#pragma unroll
+  for (int r = 0; r < G::W_ROUNDS; ++r) w_goff[r] = (unsigned)(r * G::THREADS + tid) * 16u;
+  const int wave_base = wave * 64 * 16;
+  auto issue_w = [&](int s) {
+    char *wdst = smem + 2 * G::A_BYTES + (s & 1) * G::W_BYTES + wave_base;
+#pragma unroll
+    for (int r = 0; r < G::W_ROUNDS; ++r)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void_t *)(wdst + r * G::THREADS * 16), 16, w_goff[r],
+                                               s * (G::SUB_STAGE_ITEMS * 16), 0, 0);
+  };
+  issue_w(0);  // lands under the conv1_1 prologue
+
+  // ---- prologue: conv1_1 of the halo patch; a wave owns column tiles pt = wave, wave+4, wave+8 ----
+  char *raw = smem + F::RAW_OFF + wave * F::RAW_WAVE_BYTES;
+  for (int i = lane; i < F::RAW_WAVE_BYTES / 16; i += 64) {  // 4th channel / pad columns stay 0
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    reinterpret_cast<u32x4 *>(raw)[i] = z;
+  }
+  u32x4 w1f[3][2];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      w1f[ky][i] = *reinterpret_cast<const u32x4 *>(w1m + ((ky * 64 + i * 32 + l31) * 2 + h) * 16);
+  const float mean[3] = {0.485f, 0.456f, 0.406f};
+  const float sd[3] = {0.229f, 0.224f, 0.225f};
+  int r_plan[7], r_off[7];  // item -> (row << 16 | col << 2 | c) of a 4x36x3 raw sub-patch, -1 = none
+#pragma unroll
+  for (int r = 0; r < 7; ++r) {
+    const int i = r * 64 + lane;
+    const int row = i / 108, rem = i - row * 108, col = rem / 3, c = rem - col * 3;
+    r_plan[r] = i < 432 ? (row << 16 | col << 2 | c) : -1;
+    r_off[r] = c * HW + row * W + col;
+  }
+  const float *img = (n < B ? x + (size_t)n * 3 * HW : y + (size_t)(n - B) * 3 * HW);
+  float rv[F::PT_PER_WAVE][7];
+  unsigned okm[F::PT_PER_WAVE];
+#pragma unroll
+  for (int u = 0; u < F::PT_PER_WAVE; ++u) {
+    const int pt = wave + 4 * u;
+    okm[u] = 0;
+    if (pt < F::NPT) {  // wave-uniform
+      const int r0 = (pt * 32) / G::HW_;
+      const int gy0 = y0 - 2 + r0, gx0 = x0 - 2;
+      const float *org = img + (gy0 * W + gx0);  // may point before the image: only dereferenced when ok
+#pragma unroll
+      for (int r = 0; r < 7; ++r) {
+        const int row = r_plan[r] >> 16, col = (r_plan[r] >> 2) & 0x3FFF;
+        const bool ok = r_plan[r] >= 0 && (unsigned)(gy0 + row) < (unsigned)H && (unsigned)(gx0 + col) < (unsigned)W;
+#ifdef NQA_T_NO_FETCH
+        rv[u][r] = 0.f;
+#else
+        rv[u][r] = ok ? org[r_off[r]] : 0.f;
+#endif
+        okm[u] |= ok ? (1u << r) : 0u;
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < F::PT_PER_WAVE; ++u) {
+    const int pt = wave + 4 * u;
+#ifdef NQA_T_NO_P1
+    asm volatile("" ::"v"(rv[u][0]), "v"(rv[u][3]), "v"(rv[u][6]), "v"(okm[u]));
+    if (false) {
+#else
+    if (pt < F::NPT) {
+#endif
+      const int r0 = (pt * 32) / G::HW_;
+#pragma unroll
+      for (int r = 0; r < 7; ++r) {
+        const int row = r_plan[r] >> 16, col = (r_plan[r] >> 2) & 0x3FFF, c = r_plan[r] & 3;
+        const float mu = c == 0 ? mean[0] : c == 1 ? mean[1] : mean[2], sg = c == 0 ? sd[0] : c == 1 ? sd[1] : sd[2];
+        const float v = (okm[u] >> r) & 1u ? (rv[u][r] - mu) / sg : 0.f;
+        if (r_plan[r] >= 0) *reinterpret_cast<T *>(raw + (row * F::RAW_W + col) * 8 + c * 2) = P::from_f(v);
+      }
+      // the scratch is private to this wave: its own LDS writes are ordered before its reads
+      const int q = pt * 32 + l31;
+      const int qc = q < G::NQ ? q : G::NQ - 1;
+      const int hy = qc / G::HW_, hx = qc - hy * G::HW_;
+      f32x16 a1[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a1[i][r] = 0.f;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const char *rp = raw + ((hy - r0 + ky) * F::RAW_W + hx + 2 * h) * 8;
+        const u32x2 lo = *reinterpret_cast<const u32x2 *>(rp), hi = *reinterpret_cast<const u32x2 *>(rp + 8);
+        const u32x4 bfr = {lo[0], lo[1], hi[0], hi[1]};
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a1[i] = P::mma(w1f[ky][i], bfr, a1[i]);
+      }
+      const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+      const bool inside = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      if (q < G::NQ) {
+        const int sw = (q >> 2) & 3;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bias1 + i * 32 + 8 * g + 4 * h);
+            typedef __attribute__((ext_vector_type(4))) T t4;
+            t4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = P::from_f(inside ? fmaxf(a1[i][4 * g + e] + b4[e], 0.f) : 0.f);
+            *reinterpret_cast<t4 *>(smem + i * G::A_BYTES + q * 64 + ((g ^ sw) << 4) + h * 8) = v;
+          }
+        }
+      }
+    }
+  }
+
+  // ---- conv1_2: the stage loop of conv3x3_igemm_kernel (32x32x16 path) with nothing but weights to stream ----
+  int w_base[WN_T], w_sw[WN_T];
+#pragma unroll
+  for (int i = 0; i < WN_T; ++i) {
+    const int r64 = i * 32 + l31;
+    w_base[i] = 2 * G::A_BYTES + r64 * 64;
+    w_sw[i] = (r64 >> 2) & 3;
+  }
+  int q0[WM_T];
+#pragma unroll
+  for (int j = 0; j < WM_T; ++j) {
+    const int m = (wm * WM_T + j) * 32 + l31;
+    const int ty = m / TW, tx = m - ty * TW;
+    q0[j] = ty * G::HW_ + tx;
+  }
+  f32x16 acc[WN_T][WM_T];
+#pragma unroll
+  for (int i = 0; i < WN_T; ++i)
+#pragma unroll
+    for (int j = 0; j < WM_T; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#ifdef NQA_T_NO_LOOP
+  for (int s = 0; s < 1; ++s) {
+#else
+  for (int s = 0; s < S; ++s) {
+#endif
+    const int cc = s / 3, ky = s - cc * 3;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // stage s's weights (and, at s = 0, every wave's part of the halo) are visible
+    if (s + 1 < S) issue_w(s + 1);
+    const char *abuf = smem + cc * G::A_BYTES;
+    const char *wbuf = smem + (s & 1) * G::W_BYTES;
+    auto load_frags = [&](int t, u32x4(&af)[WN_T], u32x4(&bf)[WM_T]) {
+      const int kx = t >> 1, ch = 2 * (t & 1) + h;
+#pragma unroll
+      for (int i = 0; i < WN_T; ++i)
+        af[i] = *reinterpret_cast<const u32x4 *>(wbuf + w_base[i] + kx * 4096 + ((ch ^ w_sw[i]) << 4));
+#pragma unroll
+      for (int j = 0; j < WM_T; ++j) {
+        const int q = q0[j] + ky * G::HW_ + kx;
+        bf[j] = *reinterpret_cast<const u32x4 *>(abuf + q * 64 + ((ch ^ ((q >> 2) & 3)) << 4));
+      }
+    };
+    auto mma_all = [&](const u32x4(&af)[WN_T], const u32x4(&bf)[WM_T]) {
+#pragma unroll
+      for (int i = 0; i < WN_T; ++i)
+#pragma unroll
+        for (int j = 0; j < WM_T; ++j) acc[i][j] = P::mma(af[i], bf[j], acc[i][j]);
+    };
+    u32x4 afA[WN_T], bfA[WM_T], afB[WN_T], bfB[WM_T];
+    load_frags(0, afA, bfA);
+#pragma unroll
+    for (int t = 0; t < 6; t += 2) {
+      load_frags(t + 1, afB, bfB);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_all(afA, bfA);
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 2 < 6) load_frags(t + 2, afA, bfA);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_all(afB, bfB);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // ---- epilogue: bias + ReLU, staged through LDS as in conv3x3_igemm_kernel ----
+  constexpr int RB = 64 * (int)sizeof(T), NCH = RB / 16, SWZ = NCH - 1, ROWS = 4 * 32;
+  const size_t rec = (size_t)64 * sizeof(T);
+  char *const obase = reinterpret_cast<char *>(out);
+#pragma unroll
+  for (int j = 0; j < WM_T; ++j) {
+    __syncthreads();
+    {
+      const int row = wm * 32 + l31;
+      char *const rbase = smem + row * RB;
+      const int sw = row & SWZ;
+#pragma unroll
+      for (int i = 0; i < WN_T; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int cl = i * 32 + 8 * g + 4 * h;
+          const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bias2 + cl);
+          typedef __attribute__((ext_vector_type(4))) T t4;
+          t4 s4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) s4[e] = P::from_f(fmaxf(acc[i][j][4 * g + e] + b4[e], 0.f));
+          *reinterpret_cast<t4 *>(rbase + (((cl >> 3) ^ sw) << 4) + (cl & 4) * 2) = s4;
+        }
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int idx = tid; idx < ROWS * NCH; idx += G::THREADS) {
+      const int row = idx / NCH, k = idx - row * NCH;
+      const int m = ((row >> 5) * WM_T + j) * 32 + (row & 31);
+      const int ty = m / TW, tx = m - ty * TW;
+      const int gy = y0 + ty, gx = x0 + tx;
+      if (gy < H && gx < W)
+        *reinterpret_cast<u32x4 *>(obase + ((size_t)(n * H + gy) * W + gx) * rec + k * 16) =
+            *reinterpret_cast<const u32x4 *>(smem + row * RB + ((k ^ (row & SWZ)) << 4));
+    }
+  }
+#endif
+}
+
+// ---------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------
 #ifdef NQA_STAMPS
@@ -842,7 +1108,11 @@ extern "C" int nqa_debug_stamps(unsigned long long *out8, int reset) {
 #endif
 
 static int g_conv_variant = 1;  // 0: 4-wave tiles everywhere; 1: + 8-wave 256x256 tiles; 2: + 8-wave 128x512 tiles
-void set_conv_variant(int v) { g_conv_variant = v; }
+static int g_stage1_variant = 0;  // 0: persistent two-phase kernel (conv1_fused_kernel); 1: conv1_tile_kernel
+void set_conv_variant(int v) {
+  g_conv_variant = v & 3;
+  g_stage1_variant = (v >> 2) & 1;
+}
 
 template <typename P>
 static int launch_conv1_1(const float *x, int n, int H, int W, const char *packed, void *out, hipStream_t st) {
@@ -957,10 +1227,42 @@ static int launch_conv1_fused(const float *x, const float *y, int B, int n, int 
   return check_launch("conv1_fused");
 }
 
+template <typename P>
+static int launch_conv1_tile(const float *x, const float *y, int B, int n, int H, int W, const char *packed, void *out,
+                             hipStream_t st) {
+  typedef Conv1Tile::G G;
+  constexpr int LDS = Conv1Tile::LDS_BYTES;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv1_tile_kernel<P>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+      set_error("conv1_tile: cannot raise the dynamic LDS limit to %d bytes", LDS);
+      return NQA_E_LAUNCH;
+    }
+    attr_done = true;
+  }
+  const int tiles_x = cdiv(W, 32), tiles_y = cdiv(H, G::TH);
+  dim3 grid(tiles_x * tiles_y, n);
+  const char *w1m = packed + layer0_mfma_offset(P::ID);
+  const float *b1 = reinterpret_cast<const float *>(packed + layer_bias_offset(0, P::ID));
+  const char *w2 = packed + layer_offset(1, P::ID);
+  const float *b2 = reinterpret_cast<const float *>(packed + layer_bias_offset(1, P::ID));
+  TimedLaunch t(NQA_K_CONV, st);
+  conv1_tile_kernel<P><<<grid, 256, LDS, st>>>(x, y, B, w1m, b1, w2, b2, reinterpret_cast<typename P::T *>(out), H, W,
+                                               tiles_x);
+  return check_launch("conv1_tile");
+}
+
 // stage 1 (conv1_1 + conv1_2) of images [x(0..B), y(0..n-B)) in one kernel; 16-bit modes only
 int conv1_fused(const float *x, const float *y, int B, int n, int H, int W, const void *packed, int prec, void *out,
                 hipStream_t st) {
   const char *p = static_cast<const char *>(packed);
+  if (g_stage1_variant == 1) {
+    switch (prec) {
+      case NQA_PREC_BF16: return launch_conv1_tile<PrecBF16>(x, y, B, n, H, W, p, out, st);
+      case NQA_PREC_F16: return launch_conv1_tile<PrecF16>(x, y, B, n, H, W, p, out, st);
+    }
+  }
   switch (prec) {
     case NQA_PREC_BF16: return launch_conv1_fused<PrecBF16>(x, y, B, n, H, W, p, out, st);
     case NQA_PREC_F16: return launch_conv1_fused<PrecF16>(x, y, B, n, H, W, p, out, st);

@@ -215,6 +215,9 @@ def dists_score(s1: torch.Tensor, s2: torch.Tensor, alpha: torch.Tensor, beta: t
     return out
 
 
+DEFAULT_CONV_VARIANT = 1  # the library's start-up value (include/nqa.h)
+
+
 def set_conv_variant(v: int) -> None:
     check(lib().nqa_set_conv_variant(int(v)))
 

@@ -66,7 +66,8 @@ def test_conv1_1(prec, shape, np_convs, packed, dev):
 
 @pytest.mark.parametrize("prec", ["f16", "bf16"])
 @pytest.mark.parametrize("shape", [(2, 3, 37, 53), (1, 3, 16, 16), (3, 3, 5, 70), (1, 3, 64, 96), (2, 3, 9, 33)])
-def test_conv1_fused(prec, shape, np_convs, packed, dev):
+@pytest.mark.parametrize("stage1", [0, 1], ids=["persistent", "tile"])
+def test_conv1_fused(stage1, prec, shape, np_convs, packed, dev):
     """Stage 1 in one kernel (conv1_1 on MFMA feeding conv1_2 through LDS) == the two oracle convs.
 
     conv1_1's inputs and weights are rounded to 16 bits here (they are fp32 in the two-kernel
@@ -79,7 +80,11 @@ def test_conv1_fused(prec, shape, np_convs, packed, dev):
     w0, b0 = torch.from_numpy(np_convs[0][0]), torch.from_numpy(np_convs[0][1])
     w1, b1 = torch.from_numpy(np_convs[1][0]), torch.from_numpy(np_convs[1][1])
     ref = F.relu(F.conv2d(F.relu(F.conv2d((x - mean) / std, w0, b0, padding=1)), w1, b1, padding=1))
-    out = ops.conv1_fused(x.to(dev), packed[prec], prec)
+    ops.set_conv_variant(1 | (stage1 << 2))  # both stage-1 kernels (include/nqa.h, nqa_set_conv_variant)
+    try:
+        out = ops.conv1_fused(x.to(dev), packed[prec], prec)
+    finally:
+        ops.set_conv_variant(ops.DEFAULT_CONV_VARIANT)
     assert out.dtype == DT[prec] and out.shape == (shape[0], shape[2], shape[3], 64)
     got = out.float().permute(0, 3, 1, 2).cpu()
     _close(got, ref, 3 * OUT_RTOL[prec], f"conv1_fused[{prec}] {shape}")

@@ -24,6 +24,18 @@ for (H, W, N) in ((256, 256, 64), (1080, 1920, 8)):
     e1.record()
     torch.cuda.synchronize()
     print(f"{H}x{W} N={N}: {e0.elapsed_time(e1) / 10 * 1e3:.1f} us")
+    ops.set_conv_variant(1 | 4)  # the tile form of stage 1
+    out2 = torch.empty_like(out)
+    for _ in range(3):
+        check(lib().nqa_conv1_fused(ptr(x), N, H, W, ptr(packed), 2, ptr(out2), stream_ptr(dev)))
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(10):
+        check(lib().nqa_conv1_fused(ptr(x), N, H, W, ptr(packed), 2, ptr(out2), stream_ptr(dev)))
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"   tile form: {e0.elapsed_time(e1) / 10 * 1e3:.1f} us, max |diff| vs persistent form {(out2.float() - out.float()).abs().max().item():.3e}")
+    ops.set_conv_variant(1)
     # the unfused alternative: conv1_1 (f16 NHWC out) + conv1_2 on the implicit-GEMM kernel
     a = ops.conv1_1(x, packed, "f16")
     for fn, name in ((lambda: ops.conv1_1(x, packed, "f16"), "conv1_1"), (lambda: ops.conv3x3_relu(a, 1, packed, "f16"), "conv1_2 igemm")):
