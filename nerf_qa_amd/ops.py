@@ -7,6 +7,7 @@ tensors and raise otherwise -- there is no CPU path.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Sequence
 
 import numpy as np
@@ -161,6 +162,22 @@ def vgg_pyramid(x: torch.Tensor, packed: torch.Tensor, prec, ws: Workspace | Non
     return taps
 
 
+def _max_pairs(bytes_for, b: int) -> int:
+    """Largest sub-batch whose workspace stays under NQA_MAX_WORKSPACE_GB (default 32): a batch that would
+    need more scratch than that is run in slices (pairs are independent, so the results are the same)."""
+    budget = int(float(os.environ.get("NQA_MAX_WORKSPACE_GB", "32")) * (1 << 30))
+    if b <= 1 or bytes_for(b) <= budget:
+        return b
+    lo, hi = 1, b  # bytes_for is monotone in the batch size
+    while lo < hi:
+        mid = (lo + hi + 1) // 2
+        if bytes_for(mid) <= budget:
+            lo = mid
+        else:
+            hi = mid - 1
+    return lo
+
+
 def dists_forward(x: torch.Tensor, y: torch.Tensor, packed: torch.Tensor, prec, ws: Workspace | None = None):
     """(S1, S2), each float32 (B, 1475): both pyramids + statistics in one enqueue."""
     p = prec_id(prec)
@@ -169,6 +186,10 @@ def dists_forward(x: torch.Tensor, y: torch.Tensor, packed: torch.Tensor, prec, 
     if x.shape != y.shape or x.dim() != 4 or x.shape[1] != 3:
         raise ValueError(f"expected two (B,3,H,W) tensors of equal shape, got {tuple(x.shape)} / {tuple(y.shape)}")
     b, _, h, w = x.shape
+    mb = _max_pairs(lambda n: lib().nqa_workspace_bytes(2 * n, h, w, p), b)
+    if mb < b:
+        parts = [dists_forward(x[i:i + mb], y[i:i + mb], packed, prec, ws) for i in range(0, b, mb)]
+        return torch.cat([q[0] for q in parts]), torch.cat([q[1] for q in parts])
     s1 = torch.empty((b, TOTAL_CHNS), dtype=torch.float32, device=dev)
     s2 = torch.empty((b, TOTAL_CHNS), dtype=torch.float32, device=dev)
     nbytes = lib().nqa_workspace_bytes(2 * b, h, w, p)
@@ -244,6 +265,12 @@ def adists_forward(x: torch.Tensor, y: torch.Tensor, packed: torch.Tensor, prec,
     if x.shape != y.shape or x.dim() != 4 or x.shape[1] != 3:
         raise ValueError(f"expected two (B,3,H,W) tensors of equal shape, got {tuple(x.shape)} / {tuple(y.shape)}")
     b, _, h, w = x.shape
+    mb = _max_pairs(lambda n: lib().nqa_adists_workspace_bytes(n, h, w, p), b)
+    if mb < b:
+        parts = [adists_forward(x[i:i + mb], y[i:i + mb], packed, prec, ws, with_map) for i in range(0, b, mb)]
+        if with_map:
+            return torch.cat([q[0] for q in parts]), torch.cat([q[1] for q in parts])
+        return torch.cat(parts)
     d = torch.empty((b,), dtype=torch.float32, device=dev)
     nbytes = lib().nqa_adists_workspace_bytes(b, h, w, p)
     buf = (ws or Workspace()).get(nbytes, dev)

@@ -164,3 +164,26 @@ def test_nerfqa_model_head(dev):
         if kind == "linear":
             assert abs(m.dists_weight.item() + 8) < 0.5 and abs(m.dists_bias.item() - 5) < 0.2
     cfg.regression_type = "linear"
+
+
+def test_oversized_batches_are_sliced(monkeypatch):
+    """A batch whose scratch would exceed NQA_MAX_WORKSPACE_GB runs in slices with identical results."""
+    import warnings
+    from nerf_qa_amd import ops, synth
+    from nerf_qa_amd.ADISTS import ADISTS
+    from nerf_qa_amd.DISTS_pytorch import DISTS
+    dev = torch.device("cuda:0")
+    xn, yn = synth.frame_batch(list(range(7)), 64, 80)
+    x, y = torch.from_numpy(xn).to(dev), torch.from_numpy(yn).to(dev)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m, a = DISTS().to(dev).eval(), ADISTS().to(dev).eval()
+    with torch.no_grad():
+        whole, awhole = m(x, y), a(x, y, as_loss=False)
+        per_pair = ops.lib().nqa_adists_workspace_bytes(1, 64, 80, 3)
+        monkeypatch.setenv("NQA_MAX_WORKSPACE_GB", str(2.5 * per_pair / (1 << 30)))  # room for two pairs at a time
+        assert ops._max_pairs(lambda n: ops.lib().nqa_adists_workspace_bytes(n, 64, 80, 3), 7) == 2
+        sliced, asliced = m(x, y), a(x, y, as_loss=False)
+        amap = a(x, y, as_map=True)
+    assert torch.equal(sliced, whole) and torch.equal(asliced, awhole)
+    assert amap.shape == (7, 7, 64, 80)
