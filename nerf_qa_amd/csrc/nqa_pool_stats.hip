@@ -387,7 +387,10 @@ int stats_units_per_block(int units, int C, int prec, int B) {
   const int cpc = prec == NQA_PREC_F32 ? 4 : 8;
   const int PL = 256 / (C / cpc);
   if (B < 1) B = 1;
-  long per_thread = (long)units * B / ((long)PL * 1024);
+  // ~1024 blocks over the batch, fewer for wide taps: every block leaves C*5 doubles of partial sums and
+  // the finalize pass reads them all (at C = 512, 1024 blocks are 21 MB of partials per tap)
+  const long target_blocks = C >= 512 ? 384 : (C >= 256 ? 768 : 1024);
+  long per_thread = (long)units * B / ((long)PL * target_blocks);
   per_thread = per_thread < 4 ? 4 : (per_thread > 16 ? 16 : per_thread);
   int upb = (int)per_thread * PL;
   const int max_blocks = 4096 / B > 16 ? 4096 / B : 16;
