@@ -869,8 +869,8 @@ static int adists_run(const float *x, const float *y, int B, int H, int W, const
     set_error("adists_forward: bad size or prec (B=%d H=%d W=%d prec=%d)", B, H, W, prec);
     return NQA_E_ARG;
   }
-  if ((long)H * W * 512 >= (1L << 31)) {
-    set_error("adists_forward: image too large");
+  if ((long)H * W * 64 * (long)prec_elem_bytes(prec) >= (1L << 31)) {
+    set_error("adists_forward: image too large for 32-bit in-image byte offsets");
     return NQA_E_ARG;
   }
   const APlan p = make_plan(B, H, W, prec);

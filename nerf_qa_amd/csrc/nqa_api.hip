@@ -172,7 +172,10 @@ static int run_stages(const float *x, const float *y, int nx, void *bufA, void *
   return NQA_OK;
 }
 
-static bool bad_dims(const char *who, int n, int H, int W, int prec) {
+// `chan`: the widest H x W map the call addresses with 32-bit in-image byte offsets (the conv DMA
+// plan): 64 channels for the pyramid paths (H, W are stage-1 sizes; later stages have 1/4 of the
+// pixels per doubling of the channels), the layer's own input width for the single-operator calls.
+static bool bad_dims(const char *who, int n, int H, int W, int prec, int chan = 512) {
   if (n <= 0 || H <= 0 || W <= 0) {
     set_error("%s: non-positive size n=%d H=%d W=%d", who, n, H, W);
     return true;
@@ -181,8 +184,9 @@ static bool bad_dims(const char *who, int n, int H, int W, int prec) {
     set_error("%s: unknown prec %d", who, prec);
     return true;
   }
-  if ((long)H * W * 512 >= (1L << 31)) {
-    set_error("%s: image too large for 32-bit in-image offsets (H*W*512 >= 2^31)", who);
+  if ((long)H * W * chan * (long)prec_elem_bytes(prec) >= (1L << 31)) {
+    set_error("%s: map too large for 32-bit in-image byte offsets (H*W*%d channels*%d bytes >= 2^31)", who, chan,
+              (int)prec_elem_bytes(prec));
     return true;
   }
   return false;
@@ -349,7 +353,7 @@ int nqa_conv1_1(const float *x, int n, int H, int W, const void *packed, int pre
     set_error("conv1_1: null pointer");
     return NQA_E_ARG;
   }
-  if (bad_dims("conv1_1", n, H, W, prec)) return NQA_E_ARG;
+  if (bad_dims("conv1_1", n, H, W, prec, 64)) return NQA_E_ARG;
   return conv1_1(x, n, H, W, packed, prec, out, static_cast<hipStream_t>(stream));
 }
 
@@ -358,7 +362,7 @@ int nqa_conv1_fused(const float *x, int n, int H, int W, const void *packed, int
     set_error("conv1_fused: null pointer");
     return NQA_E_ARG;
   }
-  if (bad_dims("conv1_fused", n, H, W, prec)) return NQA_E_ARG;
+  if (bad_dims("conv1_fused", n, H, W, prec, 64)) return NQA_E_ARG;
   return conv1_fused(x, nullptr, n, n, H, W, packed, prec, out, static_cast<hipStream_t>(stream));
 }
 
@@ -372,7 +376,8 @@ int nqa_conv3x3_relu(const void *in, int n, int H, int W, int layer, const void 
     set_error("conv3x3_relu: layer %d out of range 1..12", layer);
     return NQA_E_ARG;
   }
-  if (bad_dims("conv3x3_relu", n, H, W, prec)) return NQA_E_ARG;
+  if (bad_dims("conv3x3_relu", n, H, W, prec, kConvs[layer].cin > kConvs[layer].cout ? kConvs[layer].cin : kConvs[layer].cout))
+    return NQA_E_ARG;
   return conv3x3(in, n, H, W, layer, packed, prec, out, static_cast<hipStream_t>(stream));
 }
 
@@ -381,7 +386,7 @@ int nqa_l2pool(const void *in, int n, int H, int W, int C, int prec, void *out, 
     set_error("l2pool: null pointer");
     return NQA_E_ARG;
   }
-  if (bad_dims("l2pool", n, H, W, prec)) return NQA_E_ARG;
+  if (bad_dims("l2pool", n, H, W, prec, C > 0 ? C : 1)) return NQA_E_ARG;
   if (C <= 0 || C % 8) {
     set_error("l2pool: C=%d must be a positive multiple of 8", C);
     return NQA_E_SHAPE;
@@ -432,7 +437,7 @@ int nqa_vgg_pyramid(const float *x, int n, int H, int W, const void *packed, int
       set_error("vgg_pyramid: taps[%d] is null", k);
       return NQA_E_ARG;
     }
-  if (bad_dims("vgg_pyramid", n, H, W, prec)) return NQA_E_ARG;
+  if (bad_dims("vgg_pyramid", n, H, W, prec, 64)) return NQA_E_ARG;
   const size_t ab = act_bytes(n, H, W, prec);
   if (ws_bytes < 2 * ab) {
     set_error("vgg_pyramid: workspace %zu < %zu bytes", ws_bytes, 2 * ab);
@@ -450,7 +455,7 @@ int nqa_dists_forward(const float *x, const float *y, int B, int H, int W, const
     set_error("dists_forward: null pointer");
     return NQA_E_ARG;
   }
-  if (bad_dims("dists_forward", B, H, W, prec)) return NQA_E_ARG;
+  if (bad_dims("dists_forward", B, H, W, prec, 64)) return NQA_E_ARG;
   const int n = 2 * B;
   const size_t need = nqa_workspace_bytes(n, H, W, prec);
   if (ws_bytes < need) {

@@ -110,3 +110,22 @@ def test_small_and_ragged_sizes_vs_oracle(h, w, models, oracle_convs, dev):
         for key, tol in (("a32", 2e-5), ("a32s", 2e-5), ("a16", 1e-3)):
             got = models[key](x.to(dev), y.to(dev), as_loss=False).cpu()
             assert (got - aref).abs().max().item() <= tol, (key, got, aref)
+
+
+def test_4k_uhd_frame(models, dev):
+    """3840x2160: the largest map a 4-byte mode can address with 32-bit in-image offsets (H*W*64*4 < 2^31)."""
+    x, y = _frames(1, 2160, 3840, dev, 3)
+    with torch.no_grad():
+        s16, s32s = models["f16"](x, y), models["f32s"](x, y)
+        assert torch.isfinite(s16).all() and (s16 - s32s).abs().max().item() <= 1e-4
+        assert models["f16"](x, x.clone()).abs().max().item() < 2e-6
+        a = models["a32s"](x, y, as_loss=False)
+        assert torch.isfinite(a).all() and 0 < a.item() < 1
+        assert models["a32s"](x, x.clone(), as_loss=False).abs().max().item() < 1e-5
+
+
+def test_oversized_frame_is_refused(dev):
+    from nerf_qa_amd import _lib, ops
+    x = torch.zeros(1, 3, 4096, 8192, device=dev)  # 33.5 M pixels: H*W*64*2 >= 2^31
+    with pytest.raises(_lib.NqaError):
+        ops.dists_forward(x, x, torch.zeros(16, dtype=torch.uint8, device=dev), "f16")
