@@ -62,6 +62,74 @@ def import_reference():
     return RefDISTS, RefADISTS, np_convs
 
 
+VARIANT_CONFIGS = [  # (weight_lower_bound, alpha_beta_ratio, dists_weight_norm, detach_beta)
+    (0.0, 1.0, "off", "False"),
+    (2e-4, 2.0, "relu", "False"),
+    (1e-4, 0.5, "relu+w_sum_detach", "True"),
+]
+
+
+def variant_goldens(gold):
+    """The training-time variants (DISTS_pt_original / _softmax) and the NeRFQAModel head, from the reference
+    itself: scores under several run configs, project_weights, the fitted head parameters and its outputs."""
+    import pandas as pd
+    import wandb  # oracle/_standin/wandb: the attribute bag the reference reads its hyper-parameters from
+    from nerf_qa.DISTS_pytorch.DISTS_pt_original import DISTS as RefOrig
+    from nerf_qa.DISTS_pytorch.DISTS_pt_softmax import DISTS as RefSoft
+    from nerf_qa.model_stats import NeRFQAModel as RefModel
+    # the reference loads sys.prefix/weights.pt (where its packaging puts the file): serve the in-repo copy
+    real_load = torch.load
+
+    def load(path, *a, **k):
+        if os.path.basename(str(path)) == "weights.pt":
+            path = os.path.join(REF, "nerf_qa", "DISTS_pytorch", "weights.pt")
+        return real_load(path, *a, **k)
+    torch.load = load
+    cfg = wandb.config
+    cfg.subjective_score_type, cfg.regression_type = "MOS", "linear"
+    xn, yn = synth.frame_batch((11, 12), 64, 64)
+    x, y = torch.from_numpy(xn), torch.from_numpy(yn)
+    out = {"h": 64, "w": 64, "seeds": np.array((11, 12)), "weight_seed": WEIGHT_SEED,
+           "configs": np.array([[c[0], c[1]] for c in VARIANT_CONFIGS]),
+           "norms": np.array([c[2] for c in VARIANT_CONFIGS]), "detach": np.array([c[3] for c in VARIANT_CONFIGS])}
+    for i, (lb, ratio, norm, det) in enumerate(VARIANT_CONFIGS):
+        cfg.weight_lower_bound, cfg.alpha_beta_ratio, cfg.dists_weight_norm, cfg.detach_beta = lb, ratio, norm, det
+        m = RefOrig().eval()
+        with torch.no_grad():
+            s = m(x, y)
+            one = m(x[:1], y[:1])
+        assert s.shape == (2,) and one.dim() == 0
+        m.project_weights()
+        with torch.no_grad():
+            sp = m(x, y)
+        out[f"orig{i}_score"], out[f"orig{i}_one"], out[f"orig{i}_projected"] = s.numpy(), one.numpy(), sp.numpy()
+        out[f"orig{i}_alpha"], out[f"orig{i}_beta"] = m.alpha.data.numpy().reshape(-1), m.beta.data.numpy().reshape(-1)
+        print(f"variant original cfg{i}: {s.numpy()} -> projected {sp.numpy()}")
+    cfg.dists_weight_norm, cfg.detach_beta = "softmax", "False"
+    ms = RefSoft().eval()
+    with torch.no_grad():
+        out["soft_score"] = ms(x, y).numpy()
+    rng = np.random.default_rng(0)
+    d = rng.uniform(0.05, 0.4, 40)
+    mos = 5 - 8 * d + 0.01 * rng.standard_normal(40)
+    out["train_dists"], out["train_mos"] = d, mos
+    df = pd.DataFrame({"DISTS": d, "MOS": mos})
+    cfg.weight_lower_bound, cfg.alpha_beta_ratio, cfg.dists_weight_norm, cfg.detach_beta = 1e-4, 1.0, "relu", "False"
+    for kind in ("linear", "sqrt", "logistic"):
+        cfg.regression_type = kind
+        M = RefModel(df).eval()
+        with torch.no_grad():
+            scores, ds = M(x, y)
+            ent = M.entropy_loss()
+        params = [M.b1, M.b2, M.b3, M.b4] if kind == "logistic" else [M.dists_weight, M.dists_bias]
+        out[f"head_{kind}_params"] = np.array([p.item() for p in params])
+        out[f"head_{kind}_scores"], out[f"head_{kind}_dists"], out[f"head_{kind}_entropy"] = \
+            scores.numpy(), ds.numpy(), np.array(ent.item())
+        print(f"head {kind}: params {out[f'head_{kind}_params']} scores {scores.numpy()}")
+    torch.load = real_load
+    np.savez(os.path.join(gold, "variants_64x64.npz"), **out)
+
+
 def feat_summary(feats):
     return np.array([[f.mean().item(), f.abs().mean().item(), f.abs().max().item()] for f in feats], np.float64)
 
@@ -135,6 +203,8 @@ def main():
             np.savez(os.path.join(gold, f"amap_{name}.npz"),
                      h=h, w=w, seeds=np.array(seeds), kinds=np.array(kinds), weight_seed=WEIGHT_SEED,
                      shape=np.array(r_map.shape), map=r_map[:, 0].numpy())
+
+    variant_goldens(gold)
 
     # weight fingerprint so a drift of the generator is caught on the GPU box too
     fp = np.array([[float(np.abs(w_).sum()), float(b_.sum())] for w_, b_ in np_convs])
