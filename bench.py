@@ -53,6 +53,28 @@ def conv_flops_per_image(h, w):
     return ig, 2 * 9 * 3 * 64 * h * w
 
 
+def pool_bytes_per_image(h, w, esz):
+    """Algorithmic HBM bytes of the pool+statistics pass per image: taps 1..4 read once, a quarter written
+    (SURVEY 8d, L2-pool row); esz = bytes per stored activation."""
+    dims = ops.pyramid_dims(h, w)
+    total = 0
+    for k in range(4):
+        hk, wk = dims[k]
+        c = ops.CHNS[k + 1]
+        total += hk * wk * c * esz + ((hk + 1) // 2) * ((wk + 1) // 2) * c * esz
+    return total
+
+
+def hbm_roofline(launches_ms, h, w, b, steps, prec):
+    """Secondary roofline object: the HBM-bound pool+statistics kernel (algorithmic bytes / HIP-event time)."""
+    n, ms = launches_ms
+    esz = 2 if prec in ("f16", "bf16") else 4
+    ach = pool_bytes_per_image(h, w, esz) * 2 * b * steps / (ms * 1e-3) / 1e9 if ms > 0 else None
+    return {"kernel": "pool_stats_kernel (L2-pool + the five statistics sums of taps 1..4, one pass)", "bound": "hbm",
+            "achieved": round(ach, 1) if ach else None, "peak": 8000.0, "unit": "GB/s",
+            "frac": round(ach / 8000.0, 4) if ach else None, "traffic": None, "launches": n}
+
+
 def host_cores():
     """Cores this process may actually use: the cgroup CPU quota if there is one (the GPU box
     shows 256 logical CPUs but grants a 16-core share), else the affinity mask."""
@@ -212,6 +234,7 @@ def main():
                 "flop_per_launch_avg": round(ig_flops * 2 * B / launches_per_step),
             },
             "kernel_ms_per_step": {k: round(v[1] / max(steps_timed, 1), 4) for k, v in ktimes.items() if v[0]},
+            "roofline_hbm": hbm_roofline(ktimes["l2pool"], H, W, B, steps_timed, prec),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(H, W, adists=wl["metric"] == "A-DISTS")
