@@ -205,9 +205,11 @@ __global__ __launch_bounds__(256) void adists_weights_kernel(const float *__rest
 // T, S and the gamma term follow per lane; a 64-lane butterfly sums them over channels and the
 // total is banked in the accumulator of lane (row - strip start), so the strip's three output
 // columns leave as plain stores after the last channel block: no atomics, deterministic.
-struct Gauss2 {
-  float g[42];  // g[t] = gaussian[t mod 21]
-};
+// g2[t] = gaussian[t mod 21], t < 42: the doubled table the ring's vertical taps index with a moving origin
+__global__ void gauss2_fill_kernel(Gauss gw, float *__restrict__ g2) {
+  const int t = threadIdx.x;
+  if (t < 2 * kWin) g2[t] = gw.g[t % kWin];
+}
 
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
@@ -967,12 +969,12 @@ static int adists_run(const float *x, const float *y, int B, int H, int W, const
   static const Gauss gauss = make_gauss();
   float *g2 = reinterpret_cast<float *>(base + p.g2);
   {
-    static Gauss2 g2h;
-    for (int t = 0; t < 42; ++t) g2h.g[t] = gauss.g[t % kWin];
-    if (hipMemcpyAsync(g2, g2h.g, sizeof(g2h.g), hipMemcpyHostToDevice, st) != hipSuccess) {
-      set_error("adists_forward: cannot upload the window table");
-      return NQA_E_LAUNCH;
-    }
+    // the doubled window table the ring reads with a moving origin, written by the device from the
+    // kernel-argument copy of the window (stream-ordered; a host-to-device copy from pageable memory
+    // here would make every call wait for the stream)
+    TimedLaunch t(NQA_K_ADISTS, st);
+    gauss2_fill_kernel<<<1, 64, 0, st>>>(gauss, g2);
+    if ((rc = check_launch("gauss2_fill"))) return rc;
   }
   for (int k = 0; k < 6; ++k) {
     float *gamma = reinterpret_cast<float *>(base + p.maps[k][0]);

@@ -1107,6 +1107,11 @@ extern "C" int nqa_debug_stamps(unsigned long long *out8, int reset) {
 }
 #endif
 
+static int current_device() {
+  int dev = 0;
+  return hipGetDevice(&dev) == hipSuccess ? dev : 0;
+}
+
 static int g_conv_variant = 1;  // 0: 4-wave tiles everywhere; 1: + 8-wave 256x256 tiles; 2: + 8-wave 128x512 tiles
 static int g_stage1_variant = 0;  // 0: persistent two-phase kernel (conv1_fused_kernel); 1: conv1_tile_kernel
 void set_conv_variant(int v) {
@@ -1128,7 +1133,8 @@ template <typename P, int WAVES_N, int WAVES_M, int WN_T, int WM_T, int TW, bool
 static int launch_igemm(const void *in, int n, int H, int W, int cin, int cout, const char *wpk, const float *bias,
                         void *out, int out_split, hipStream_t st) {
   typedef ConvGeom<WAVES_N, WAVES_M, WN_T, WM_T, TW> G;
-  static bool attr_done = false;
+  static bool attr_done_dev[64] = {false};  // the attribute is per device: a process may drive several
+  bool &attr_done = attr_done_dev[current_device() & 63];
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_igemm_kernel<P, WAVES_N, WAVES_M, WN_T, WM_T, TW, M16>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES) != hipSuccess) {
@@ -1197,7 +1203,8 @@ template <typename P>
 static int launch_conv1_fused(const float *x, const float *y, int B, int n, int H, int W, const char *packed,
                               void *out, hipStream_t st) {
   constexpr int LDS = Conv1Fused::LDS_BYTES;
-  static bool attr_done = false;
+  static bool attr_done_dev[64] = {false};  // the attribute is per device: a process may drive several
+  bool &attr_done = attr_done_dev[current_device() & 63];
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv1_fused_kernel<P>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
@@ -1232,7 +1239,8 @@ static int launch_conv1_tile(const float *x, const float *y, int B, int n, int H
                              hipStream_t st) {
   typedef Conv1Tile::G G;
   constexpr int LDS = Conv1Tile::LDS_BYTES;
-  static bool attr_done = false;
+  static bool attr_done_dev[64] = {false};  // the attribute is per device: a process may drive several
+  bool &attr_done = attr_done_dev[current_device() & 63];
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv1_tile_kernel<P>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
