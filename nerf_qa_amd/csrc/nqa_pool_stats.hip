@@ -65,36 +65,45 @@ __global__ __launch_bounds__(256) void l2pool_kernel(const typename P::T *__rest
 // thread's first sample of that channel, so the sums are of the order of the variance -- and
 // converts them to raw fp64 sums once, at the end; block partials and the final combine are
 // fp64.  Every feature byte is read once and the error stays relative to the variance.
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
 template <int N>
-struct ShiftedMoments {
-  float px[N], py[N];            // pivots
-  float s1x[N], s1y[N], s2x[N], s2y[N], sxy[N];
+struct ShiftedMoments {  // N channels held as N/2 float pairs, so every update is packed (v_pk_*_f32)
+  f32x2 px[N / 2], py[N / 2];  // pivots
+  f32x2 s1x[N / 2], s1y[N / 2], s2x[N / 2], s2y[N / 2], sxy[N / 2];
   int n;
   __device__ inline void init() {
     n = 0;
 #pragma unroll
-    for (int e = 0; e < N; ++e) px[e] = py[e] = s1x[e] = s1y[e] = s2x[e] = s2y[e] = sxy[e] = 0.f;
+    for (int e = 0; e < N / 2; ++e) px[e] = py[e] = s1x[e] = s1y[e] = s2x[e] = s2y[e] = sxy[e] = (f32x2){0.f, 0.f};
   }
-  __device__ inline void add(int e, float x, float y) {
-    const float dx = x - px[e], dy = y - py[e];
-    s1x[e] += dx;
-    s1y[e] += dy;
-    s2x[e] = fmaf(dx, dx, s2x[e]);
-    s2y[e] = fmaf(dy, dy, s2y[e]);
-    sxy[e] = fmaf(dx, dy, sxy[e]);
+  __device__ inline void add2(int e2, f32x2 x, f32x2 y) {
+    const f32x2 dx = x - px[e2], dy = y - py[e2];
+    s1x[e2] += dx;
+    s1y[e2] += dy;
+    s2x[e2] = dx * dx + s2x[e2];
+    s2y[e2] = dy * dy + s2y[e2];
+    sxy[e2] = dx * dy + sxy[e2];
   }
   // raw sum s of channel e, s = {sum x, sum y, sum x^2, sum y^2, sum xy}
   __device__ inline double raw(int e, int s) const {
-    const double p = px[e], q = py[e], nn = n, ax = s1x[e], ay = s1y[e];
+    const int e2 = e >> 1, k = e & 1;
+    const double p = px[e2][k], q = py[e2][k], nn = n, ax = s1x[e2][k], ay = s1y[e2][k];
     switch (s) {
       case 0: return ax + nn * p;
       case 1: return ay + nn * q;
-      case 2: return (double)s2x[e] + 2.0 * p * ax + nn * p * p;
-      case 3: return (double)s2y[e] + 2.0 * q * ay + nn * q * q;
-      default: return (double)sxy[e] + q * ax + p * ay + nn * p * q;
+      case 2: return (double)s2x[e2][k] + 2.0 * p * ax + nn * p * p;
+      case 3: return (double)s2y[e2][k] + 2.0 * q * ay + nn * q * q;
+      default: return (double)sxy[e2][k] + q * ax + p * ay + nn * p * q;
     }
   }
 };
+// one loaded 16-byte channel group as float pairs
+template <typename P, typename V>
+__device__ inline void unpack2(const V &v, f32x2 (&out)[P::CPC / 2]) {
+#pragma unroll
+  for (int e = 0; e < P::CPC / 2; ++e) out[e] = (f32x2){P::to_f(v[2 * e]), P::to_f(v[2 * e + 1])};
+}
 
 // Block reduction of the per-thread raw sums over the pixel lanes -> part[(b*nblk+blk)*C*5 ...].
 template <int CPC>
@@ -148,53 +157,81 @@ __global__ __launch_bounds__(256) void pool_stats_kernel(const typename P::T *__
     const int oy = min(oy0 + pl / TC, Ho - 1), ox = min(ox0 + pl % TC, Wo - 1);
     const size_t o = ((size_t)(2 * oy) * W + 2 * ox) * C;
     const tvec vx = *reinterpret_cast<const tvec *>(fx + o), vy = *reinterpret_cast<const tvec *>(fy + o);
-#pragma unroll
-    for (int e = 0; e < P::CPC; ++e) {
-      m.px[e] = P::to_f(vx[e]);
-      m.py[e] = P::to_f(vy[e]);
-    }
+    unpack2<P>(vx, m.px);
+    unpack2<P>(vy, m.py);
   }
   for (int t = pl; t < tile_units; t += PL) {
     const int oy = oy0 + t / TC, ox = ox0 + t % TC;
     if (oy >= Ho || ox >= Wo) continue;
     const int u = oy * Wo + ox;
-    // All 18 loads go out unconditionally from clamped coordinates, back to back (a branch per
-    // tap would serialise them into 9 round trips); an out-of-image tap is then zeroed for the
-    // pool (zero padding) and skipped by the sums.
+    // All 18 loads go out unconditionally, back to back (a branch per tap would serialise them into
+    // 9 round trips).  A window that lies wholly inside the image -- almost all of them -- takes the
+    // fast path: addresses are one base plus constants, every tap is live, no selects; at the image
+    // border the coordinates are clamped, and an out-of-image tap is zeroed for the pool (zero
+    // padding) and replaced by the pivot for the sums (it then adds exactly 0).
+    const int iy0 = 2 * oy - 1, ix0 = 2 * ox - 1;
+    const bool interior = iy0 >= 0 && iy0 + 2 < H && ix0 >= 0 && ix0 + 2 < W;
     tvec vx[9], vy[9];
+    if (interior) {
+      const size_t o0 = ((size_t)iy0 * W + ix0) * C;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int cy = min(max(2 * oy - 1 + t / 3, 0), H - 1), cx = min(max(2 * ox - 1 + t % 3, 0), W - 1);
-      const size_t o = ((size_t)cy * W + cx) * C;
-      vx[t] = *reinterpret_cast<const tvec *>(fx + o);
-      vy[t] = *reinterpret_cast<const tvec *>(fy + o);
+      for (int t = 0; t < 9; ++t) {
+        const size_t o = o0 + ((size_t)(t / 3) * W + (t % 3)) * C;
+        vx[t] = *reinterpret_cast<const tvec *>(fx + o);
+        vy[t] = *reinterpret_cast<const tvec *>(fy + o);
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int cy = min(max(iy0 + t / 3, 0), H - 1), cx = min(max(ix0 + t % 3, 0), W - 1);
+        const size_t o = ((size_t)cy * W + cx) * C;
+        vx[t] = *reinterpret_cast<const tvec *>(fx + o);
+        vy[t] = *reinterpret_cast<const tvec *>(fy + o);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);  // keep the 18 loads ahead of all the arithmetic
-    float px[P::CPC], py[P::CPC];
+    f32x2 qx[P::CPC / 2], qy[P::CPC / 2];
 #pragma unroll
-    for (int e = 0; e < P::CPC; ++e) px[e] = py[e] = 0.f;
+    for (int e = 0; e < P::CPC / 2; ++e) qx[e] = qy[e] = (f32x2){0.f, 0.f};
+    if (interior) {
+      m.n += 4;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int dy = t / 3, dx = t % 3;
-      const int iy = 2 * oy - 1 + dy, ix = 2 * ox - 1 + dx;
-      const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-      const float wgt = ok ? ((dy == 1) ? 0.5f : 0.25f) * ((dx == 1) ? 0.5f : 0.25f) : 0.f;
-      if (dy >= 1 && dx >= 1 && ok) m.n += 1;
+      for (int t = 0; t < 9; ++t) {
+        const int dy = t / 3, dx = t % 3;
+        const float wgt = ((dy == 1) ? 0.5f : 0.25f) * ((dx == 1) ? 0.5f : 0.25f);
+        f32x2 X[P::CPC / 2], Y[P::CPC / 2];
+        unpack2<P>(vx[t], X);
+        unpack2<P>(vy[t], Y);
 #pragma unroll
-      for (int e = 0; e < P::CPC; ++e) {
-        const float x = P::to_f(vx[t][e]), y = P::to_f(vy[t][e]);
-        px[e] = fmaf(x * x, wgt, px[e]);
-        py[e] = fmaf(y * y, wgt, py[e]);
-        if (dy >= 1 && dx >= 1) {
-          // an out-of-image owned tap is replaced by the pivot: it adds exactly 0 to every sum
-          m.add(e, ok ? x : m.px[e], ok ? y : m.py[e]);
+        for (int e = 0; e < P::CPC / 2; ++e) {
+          qx[e] = (X[e] * X[e]) * wgt + qx[e];
+          qy[e] = (Y[e] * Y[e]) * wgt + qy[e];
+          if (dy >= 1 && dx >= 1) m.add2(e, X[e], Y[e]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int dy = t / 3, dx = t % 3;
+        const bool ok = (unsigned)(iy0 + dy) < (unsigned)H && (unsigned)(ix0 + dx) < (unsigned)W;
+        const float wgt = ok ? ((dy == 1) ? 0.5f : 0.25f) * ((dx == 1) ? 0.5f : 0.25f) : 0.f;
+        if (dy >= 1 && dx >= 1 && ok) m.n += 1;
+        f32x2 X[P::CPC / 2], Y[P::CPC / 2];
+        unpack2<P>(vx[t], X);
+        unpack2<P>(vy[t], Y);
+#pragma unroll
+        for (int e = 0; e < P::CPC / 2; ++e) {
+          qx[e] = (X[e] * X[e]) * wgt + qx[e];
+          qy[e] = (Y[e] * Y[e]) * wgt + qy[e];
+          if (dy >= 1 && dx >= 1) m.add2(e, ok ? X[e] : m.px[e], ok ? Y[e] : m.py[e]);
         }
       }
     }
+    float px[P::CPC], py[P::CPC];
 #pragma unroll
     for (int e = 0; e < P::CPC; ++e) {
-      px[e] = sqrtf(px[e] + 1e-12f);
-      py[e] = sqrtf(py[e] + 1e-12f);
+      px[e] = sqrtf(qx[e >> 1][e & 1] + 1e-12f);
+      py[e] = sqrtf(qy[e >> 1][e & 1] + 1e-12f);
     }
     store_group<P>(ox_ + (size_t)u * C, g * P::CPC, px);
     store_group<P>(oy_ + (size_t)u * C, g * P::CPC, py);
@@ -224,19 +261,19 @@ __global__ __launch_bounds__(256) void stats_nhwc_kernel(const typename P::T *__
   if (p_begin + pl < p_end) {
     const tvec vx = *reinterpret_cast<const tvec *>(fx + (size_t)(p_begin + pl) * C);
     const tvec vy = *reinterpret_cast<const tvec *>(fy + (size_t)(p_begin + pl) * C);
-#pragma unroll
-    for (int e = 0; e < P::CPC; ++e) {
-      m.px[e] = P::to_f(vx[e]);
-      m.py[e] = P::to_f(vy[e]);
-    }
+    unpack2<P>(vx, m.px);
+    unpack2<P>(vy, m.py);
   }
 #pragma unroll 4
   for (int p = p_begin + pl; p < p_end; p += PL) {
     const tvec vx = *reinterpret_cast<const tvec *>(fx + (size_t)p * C);
     const tvec vy = *reinterpret_cast<const tvec *>(fy + (size_t)p * C);
     m.n += 1;
+    f32x2 X[P::CPC / 2], Y[P::CPC / 2];
+    unpack2<P>(vx, X);
+    unpack2<P>(vy, Y);
 #pragma unroll
-    for (int e = 0; e < P::CPC; ++e) m.add(e, P::to_f(vx[e]), P::to_f(vy[e]));
+    for (int e = 0; e < P::CPC / 2; ++e) m.add2(e, X[e], Y[e]);
   }
   reduce_store<P::CPC>(m, red, tid, G, PL, C, part + ((size_t)b * nblk + blk) * C * 5);
 }

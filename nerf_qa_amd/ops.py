@@ -163,9 +163,9 @@ def vgg_pyramid(x: torch.Tensor, packed: torch.Tensor, prec, ws: Workspace | Non
 
 
 def _max_pairs(bytes_for, b: int) -> int:
-    """Largest sub-batch whose workspace stays under NQA_MAX_WORKSPACE_GB (default 32): a batch that would
-    need more scratch than that is run in slices (pairs are independent, so the results are the same)."""
-    budget = int(float(os.environ.get("NQA_MAX_WORKSPACE_GB", "32")) * (1 << 30))
+    """Slice size for a batch whose workspace would exceed NQA_MAX_WORKSPACE_GB (default 96, a third of an
+    MI355X's HBM): the batch then runs in equal slices (pairs are independent, so the results are the same)."""
+    budget = int(float(os.environ.get("NQA_MAX_WORKSPACE_GB", "96")) * (1 << 30))
     if b <= 1 or bytes_for(b) <= budget:
         return b
     lo, hi = 1, b  # bytes_for is monotone in the batch size
@@ -175,7 +175,8 @@ def _max_pairs(bytes_for, b: int) -> int:
             lo = mid
         else:
             hi = mid - 1
-    return lo
+    slices = -(-b // lo)
+    return -(-b // slices)  # equal slices rather than full ones plus a remainder
 
 
 def dists_forward(x: torch.Tensor, y: torch.Tensor, packed: torch.Tensor, prec, ws: Workspace | None = None):

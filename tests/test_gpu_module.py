@@ -182,7 +182,7 @@ def test_oversized_batches_are_sliced(monkeypatch):
         whole, awhole = m(x, y), a(x, y, as_loss=False)
         per_pair = ops.lib().nqa_adists_workspace_bytes(1, 64, 80, 3)
         monkeypatch.setenv("NQA_MAX_WORKSPACE_GB", str(2.5 * per_pair / (1 << 30)))  # room for two pairs at a time
-        assert ops._max_pairs(lambda n: ops.lib().nqa_adists_workspace_bytes(n, 64, 80, 3), 7) == 2
+        assert ops._max_pairs(lambda n: ops.lib().nqa_adists_workspace_bytes(n, 64, 80, 3), 7) == 2  # 2,2,2,1
         sliced, asliced = m(x, y), a(x, y, as_loss=False)
         amap = a(x, y, as_map=True)
     assert torch.equal(sliced, whole) and torch.equal(asliced, awhole)
