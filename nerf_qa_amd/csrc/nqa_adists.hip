@@ -751,7 +751,7 @@ static APlan make_plan(int B, int H, int W, int prec) {
     off += align_up(bytes, 256);
     return o;
   };
-  const size_t act = (size_t)2 * B * H * W * 64 * esz;
+  const size_t act = (size_t)2 * B * max_act_elems(H, W) * esz;  // not H*W*64: tiny frames peak at a later stage
   p.bufA = take(act);
   p.bufB = take(act);
   for (int k = 0; k < 5; ++k) p.taps[k] = take((size_t)2 * B * p.h[k + 1] * p.w[k + 1] * p.c[k + 1] * esz);

@@ -127,8 +127,22 @@ static PyrDims pyr_dims(int H, int W) {
   return d;
 }
 
+// Elements of the largest activation map of the pyramid, per image.  For ordinary frames that is
+// stage 1 (H*W*64), but the maps shrink by ceil(./2) while the channels double, so below ~8 pixels
+// a side a LATER stage is the largest (a 1x1 frame: 64 elements at stage 1, 512 at stages 4 and 5);
+// sizing the ping-pong buffers by stage 1 alone let those stages write past them.
+size_t max_act_elems(int H, int W) {
+  static const int kStageC[5] = {64, 128, 256, 512, 512};
+  const PyrDims d = pyr_dims(H, W);
+  size_t m = 0;
+  for (int k = 0; k < 5; ++k) {
+    const size_t e = (size_t)d.h[k] * d.w[k] * kStageC[k];
+    m = e > m ? e : m;
+  }
+  return m;
+}
 static size_t act_bytes(int n, int H, int W, int prec) {
-  return align_up((size_t)n * H * W * 64 * prec_elem_bytes(prec), 256);
+  return align_up((size_t)n * max_act_elems(H, W) * prec_elem_bytes(prec), 256);
 }
 
 // Runs the 13 convs and the four L2-pools on `n` images: images [0,nx) come from x, the rest from

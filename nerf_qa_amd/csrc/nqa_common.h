@@ -157,6 +157,8 @@ struct StageDesc {
   int ctot;
 };
 
+size_t max_act_elems(int H, int W);  // largest activation map of the pyramid, elements per image (nqa_api.hip)
+
 // ---- host launchers shared between translation units ---------------------------------
 void set_conv_variant(int v);
 int conv1_1(const float *x, int n, int H, int W, const void *packed, int prec, void *out, hipStream_t st);

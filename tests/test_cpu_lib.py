@@ -125,6 +125,20 @@ def test_pack_split_f16(np_convs, lib):
         assert np.array_equal(bias, np_convs[l][1])
 
 
+@pytest.mark.parametrize("h,w", [(1, 1), (2, 3), (1, 12), (3, 2), (7, 7), (64, 64)])
+def test_workspace_covers_the_largest_stage(h, w, lib):
+    """Below ~8 pixels a side a LATER stage's map is the largest (ceil(./2) pixels, doubling channels): the
+    ping-pong buffers must be sized for it (a 1x1 frame: 64 elements at stage 1, 512 at stages 4 and 5)."""
+    chans = (64, 128, 256, 512, 512)
+    hk, wk, biggest = h, w, 0
+    for c in chans:
+        biggest = max(biggest, hk * wk * c)
+        hk, wk = (hk + 1) // 2, (wk + 1) // 2
+    for prec, esz in ((0, 4), (2, 2), (3, 4)):
+        assert lib.nqa_workspace_bytes(4, h, w, prec) >= 2 * 4 * biggest * esz
+        assert lib.nqa_adists_workspace_bytes(2, h, w, prec) >= 2 * 4 * biggest * esz
+
+
 def test_no_cpu_fallback():
     """CPU tensors must be refused, not silently computed somewhere else."""
     from nerf_qa_amd import _lib, ops
