@@ -49,3 +49,74 @@ def test_random_shape(h, w, models, oracle_convs):
         assert torch.equal(torch.isnan(got), torch.isnan(aref)), ("a32s", h, w, got, aref)
         ok = ~torch.isnan(aref)
         assert not ok.any() or (got[ok] - aref[ok]).abs().max().item() <= 2e-5, ("a32s", h, w, got, aref)
+
+
+class _GuardedWorkspace:
+    """ops.Workspace stand-in: hands out exactly the bytes asked for, fenced by guard bytes on both sides."""
+    GUARD = 1 << 16
+
+    def __init__(self):
+        self.full = None
+        self.n = 0
+
+    def get(self, nbytes, dev):
+        self.n = max(int(nbytes), 256)
+        self.full = torch.full((self.n + 2 * self.GUARD,), 0xA5, dtype=torch.uint8, device=dev)
+        return self.full[self.GUARD:self.GUARD + self.n]
+
+    def intact(self):
+        g = self.GUARD
+        return bool((self.full[:g] == 0xA5).all() and (self.full[g + self.n:] == 0xA5).all())
+
+
+@pytest.mark.parametrize("prec", ["f16", "f32s"])
+@pytest.mark.parametrize("h,w", [(1, 1), (2, 3), (1, 12), (3, 2), (7, 9), (17, 40), (33, 2), (64, 48), (97, 131)],
+                         ids=lambda v: str(v))
+def test_no_write_outside_the_workspace(h, w, prec, np_convs):
+    """Every fused entry point with a fenced workspace and fenced outputs: the fences must survive."""
+    from nerf_qa_amd import ops, synth
+    dev = torch.device("cuda:0")
+    packed = ops.pack_vgg_weights(np_convs, prec).to(dev)
+    xn, yn = synth.frame_batch([5, 6], h, w)
+    x, y = torch.from_numpy(xn).to(dev), torch.from_numpy(yn).to(dev)
+    for call in (lambda ws: ops.dists_forward(x, y, packed, prec, ws),
+                 lambda ws: ops.vgg_pyramid(x, packed, prec, ws),
+                 lambda ws: ops.adists_forward(x, y, packed, prec, ws, with_map=True)):
+        ws = _GuardedWorkspace()
+        call(ws)
+        torch.cuda.synchronize()
+        assert ws.intact(), f"{h}x{w} {prec}: a kernel wrote outside its workspace"
+
+
+_rng2 = np.random.default_rng(77)
+OP_CASES = [(int(l), int(n), int(h), int(w)) for l, n, h, w in zip(
+    _rng2.choice([1, 2, 3, 4, 6, 7, 9, 10, 12], 24), _rng2.integers(1, 4, 24), _rng2.integers(1, 41, 24),
+    _rng2.integers(1, 71, 24))] + [(8, 1, 8, 16), (8, 1, 8, 17), (5, 2, 9, 32), (5, 2, 9, 33), (3, 1, 4, 15), (12, 2, 1, 1)]
+
+
+@pytest.mark.parametrize("prec", ["f16", "bf16", "f32", "f32s"])
+@pytest.mark.parametrize("layer,n,h,w", OP_CASES, ids=[f"L{c[0]}-{c[1]}x{c[2]}x{c[3]}" for c in OP_CASES])
+def test_random_conv_layer(layer, n, h, w, prec, np_convs):
+    """One conv layer at a random ragged size (every tile variant: 16- and 32-wide, 4- and 8-wave) vs F.conv2d."""
+    import torch.nn.functional as F
+    from nerf_qa_amd import ops, synth
+    dev = torch.device("cuda:0")
+    dt = {"f16": torch.float16, "bf16": torch.bfloat16}.get(prec, torch.float32)
+    rtol = {"f16": 1.2e-3, "bf16": 9e-3}.get(prec, 2e-5)
+    cin = ops.CONV_CIN[layer]
+    a = torch.from_numpy((synth.uniform(layer * 1000 + h * 71 + w, n * h * w * cin) * 4 - 2).astype(np.float32)
+                         .reshape(n, h, w, cin)).clamp_min(0).to(dt)
+    wq = torch.from_numpy(np_convs[layer][0]).to(dt).float()
+    ref = F.relu(F.conv2d(a.float().permute(0, 3, 1, 2), wq, torch.from_numpy(np_convs[layer][1]), padding=1))
+    packed = ops.pack_vgg_weights(np_convs, prec).to(dev)
+    inp = ops.split16_encode(a.to(dev)) if prec == "f32s" else a.to(dev)
+    for variant in (0, 1, 2):
+        ops.set_conv_variant(variant)
+        try:
+            out = ops.conv3x3_relu(inp, layer, packed, prec)
+        finally:
+            ops.set_conv_variant(ops.DEFAULT_CONV_VARIANT)
+        got = (ops.split16_decode(out) if prec == "f32s" and layer not in ops.TAP_LAYERS else out.float())
+        got = got.permute(0, 3, 1, 2).cpu()
+        err = (got - ref).abs().max().item()
+        assert err <= rtol * (ref.abs().max().item() + 1e-30), (layer, n, h, w, prec, variant, err)
