@@ -120,3 +120,37 @@ def test_random_conv_layer(layer, n, h, w, prec, np_convs):
         got = got.permute(0, 3, 1, 2).cpu()
         err = (got - ref).abs().max().item()
         assert err <= rtol * (ref.abs().max().item() + 1e-30), (layer, n, h, w, prec, variant, err)
+
+
+@pytest.mark.parametrize("h,w", [(21, 21), (22, 45), (37, 53), (64, 80), (20, 50), (43, 21), (90, 97)], ids=lambda v: str(v))
+def test_random_adists_map(h, w, models, oracle_convs):
+    """as_map=True at sizes around the 21-pixel window switch (stage 0 windowed or not, later stages global)."""
+    from nerf_qa_amd import synth
+    from oracle import adists_oracle
+    dev = torch.device("cuda:0")
+    xn, yn = synth.frame_batch([h, w], h, w, ["blur", "noise10"])
+    x, y = torch.from_numpy(xn), torch.from_numpy(yn)
+    ref = adists_oracle.adists(x, y, oracle_convs, as_map=True)
+    with torch.no_grad():
+        got = models["a32s"](x.to(dev), y.to(dev), as_map=True).cpu()
+    assert got.shape == ref.shape == (2, 2, h, w)
+    # 21x21: the stage-0 window map is a single value whose unbiased std is NaN in the reference -- and here
+    assert torch.equal(torch.isnan(got), torch.isnan(ref))
+    ok = ~torch.isnan(ref)
+    assert not ok.any() or (got[ok] - ref[ok]).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize("prec", ["f16", "f32", "f32s"])
+@pytest.mark.parametrize("n,h,w,c", [(1, 1, 1, 64), (2, 3, 2, 128), (1, 5, 33, 64), (3, 2, 7, 512), (1, 31, 1, 256),
+                                     (2, 18, 19, 128)], ids=lambda v: str(v))
+def test_random_l2pool(n, h, w, c, prec):
+    from nerf_qa_amd import ops, synth
+    from oracle import dists_oracle
+    dev = torch.device("cuda:0")
+    dt = torch.float16 if prec == "f16" else torch.float32
+    a = torch.from_numpy((synth.uniform(n * 7 + h * 13 + w, n * h * w * c) * 3).astype(np.float32).reshape(n, h, w, c)).to(dt)
+    ref = dists_oracle.l2pool(a.float().permute(0, 3, 1, 2))
+    out = ops.l2pool(a.to(dev), prec)
+    got = (ops.split16_decode(out) if prec == "f32s" else out.float()).permute(0, 3, 1, 2).cpu()
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() <= (1.2e-3 if prec == "f16" else 2e-5) * ref.abs().max().item()
