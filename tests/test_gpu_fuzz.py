@@ -154,3 +154,27 @@ def test_random_l2pool(n, h, w, c, prec):
     got = (ops.split16_decode(out) if prec == "f32s" else out.float()).permute(0, 3, 1, 2).cpu()
     assert got.shape == ref.shape
     assert (got - ref).abs().max().item() <= (1.2e-3 if prec == "f16" else 2e-5) * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("h,w,b", [(1, 1, 1), (2, 3, 3), (9, 4, 2), (40, 70, 1), (130, 67, 2)], ids=lambda v: str(v))
+def test_random_from_feats(h, w, b):
+    """forward_from_feats' statistics on caller-provided float NCHW pyramids of odd sizes (stats_nchw_kernel)."""
+    from nerf_qa_amd import ops, synth
+    from oracle import dists_oracle
+    dev = torch.device("cuda:0")
+    chns = (3, 64, 128, 256, 512, 512)
+    dims, hh, ww = [(h, w)], h, w
+    for k in range(5):
+        if k:
+            hh, ww = (hh + 1) // 2, (ww + 1) // 2
+        dims.append((hh, ww))
+    mk = lambda seed, shape: torch.from_numpy((synth.uniform(seed, int(np.prod(shape))) * 2).astype(np.float32).reshape(shape))
+    f0 = [mk(50 + k, (b, c, dh, dw)) for k, (c, (dh, dw)) in enumerate(zip(chns, dims))]
+    f1 = [(f + 0.25 * (mk(80 + k, tuple(f.shape)) - 1)).clamp_min(0) for k, f in enumerate(f0)]
+    # the oracle in float64: with 1-2 pixel maps a channel's variance can sit at 1e-5, where the reference's own
+    # float32 two-pass variance is only good to 1e-2 relative; the kernel (fp64 sums) is compared with the exact value
+    r1, r2 = dists_oracle.dists_stats([f.double() for f in f0], [f.double() for f in f1])
+    r1, r2 = r1.float(), r2.float()
+    s1, s2 = ops.dists_stats_nchw([f.to(dev) for f in f0], [f.to(dev) for f in f1])
+    e1, e2 = (s1.cpu() - r1).abs(), (s2.cpu() - r2).abs()
+    assert e1.max().item() <= 2e-6 and e2.max().item() <= 2e-5, (e1.max().item(), e2.max().item(), int(e2.argmax()) % 1475)
