@@ -178,3 +178,26 @@ def test_random_from_feats(h, w, b):
     s1, s2 = ops.dists_stats_nchw([f.to(dev) for f in f0], [f.to(dev) for f in f1])
     e1, e2 = (s1.cpu() - r1).abs(), (s2.cpu() - r2).abs()
     assert e1.max().item() <= 2e-6 and e2.max().item() <= 2e-5, (e1.max().item(), e2.max().item(), int(e2.argmax()) % 1475)
+
+
+_rng3 = np.random.default_rng(5)
+RESIZE_CASES = [(int(a), int(b), int(c), int(d)) for a, b, c, d in zip(
+    _rng3.integers(1, 400, 20), _rng3.integers(1, 500, 20), _rng3.integers(1, 300, 20), _rng3.integers(1, 300, 20))] + \
+    [(1, 1, 7, 5), (2, 2, 1, 1), (1080, 1920, 256, 256), (300, 1, 10, 1)]
+
+
+@pytest.mark.parametrize("hin,win,hout,wout", RESIZE_CASES, ids=[f"{a}x{b}-{c}x{d}" for a, b, c, d in RESIZE_CASES])
+def test_random_resize(hin, win, hout, wout):
+    """Random up- and down-scales: bit-exact with the installed Pillow, 1e-6 from F.interpolate."""
+    import torch.nn.functional as F
+    from PIL import Image
+    from nerf_qa_amd import ops, synth
+    dev = torch.device("cuda:0")
+    img = (synth.uniform(hin * 1000 + win, hin * win * 3) * 256).astype(np.uint8).reshape(1, hin, win, 3)
+    d = torch.from_numpy(img).to(dev)
+    got = ops.resize_pil_bilinear_u8(d, (hout, wout)).cpu().numpy()[0]
+    want = np.asarray(Image.fromarray(img[0]).resize((wout, hout), Image.BILINEAR))
+    assert np.array_equal(got, want), np.abs(got.astype(int) - want).max()
+    x = torch.from_numpy(img).permute(0, 3, 1, 2).float() / 255.0
+    ref = F.interpolate(x, size=(hout, wout), mode="bilinear", align_corners=False)
+    assert (ops.u8_resize_bilinear_f32(d, (hout, wout)).cpu() - ref).abs().max().item() <= 1e-6
