@@ -14,9 +14,14 @@
 //                       LDS-DMA, double-buffered, one barrier per stage.
 //
 // LDS images are rows of 64 bytes (one pixel or one output channel, 4 chunks of 16 B).
-// Chunk c of row r sits at position c ^ ((r>>2)&3): the 16 lanes that ds_read_b128 serves
-// together read 16 consecutive rows at one logical chunk, and the XOR spreads them over
-// all 16 slots of the 256-byte bank row (cdna guide section 2 / T2).
+// Chunk c of row r sits at position c ^ lds_swz(r), chosen per MFMA shape so that every
+// ds_read_b128 lane group covers all 16 slots of the 256-byte bank row from any base row:
+// (r>>2)&3 for the 32x32x16 reads (32 consecutive rows, one chunk), 2*((r>>2)&1) for the
+// 16x16x32 reads (16 consecutive rows, all four chunks) -- cdna guide section 2 / T2.
+//
+// Three more kernels live here: conv1_fused_kernel and conv1_tile_kernel (stage 1 without its HBM
+// intermediate, two forms) and the precision variants of the implicit GEMM (f32: exact-f32 MFMA;
+// f32s: split-f16 products on split16 activations; 16-bit: v_mfma_f32_16x16x32).
 #include "nqa_common.h"
 
 namespace nqa {
