@@ -28,6 +28,7 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str |
     ablations) next to the product library; NQA_LIB selects it at load time.
     """
     lib = out or LIB
+    variant = out is not None
     if not force and not extra_flags and not _stale():
         return LIB
     objs = []
@@ -51,6 +52,9 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str |
         raise RuntimeError("libnqa_hip.so: compilation failed")
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib]
     subprocess.run(cmd, check=True)
+    if variant:  # a development variant's objects are not reused: do not let them pile up
+        for o in objs:
+            os.remove(o)
     return lib
 
 
