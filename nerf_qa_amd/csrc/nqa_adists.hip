@@ -213,6 +213,14 @@ __global__ void gauss2_fill_kernel(Gauss gw, float *__restrict__ g2) {
 
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
+// a / b to ~1.5 ulp from v_rcp_f32 and one Newton step: 4 instructions where the IEEE sequence is ~10.
+// Used for the three quotients per (output row, channel) of the window pass (b > 0 there).
+__device__ inline float div_nr(float a, float b) {
+  float r = __builtin_amdgcn_rcpf(b);
+  r = fmaf(fmaf(-b, r, 1.f), r, r);
+  return a * r;
+}
+
 // One DPP move of a float (ctrl is an instruction immediate); lanes outside row_mask get 0.
 template <int CTRL, int ROW_MASK>
 __device__ inline float dpp0(float v) {
@@ -315,12 +323,12 @@ __global__ __launch_bounds__(256, 2) void adists_window_lanes_kernel(
                 m4 = fmaf(wv, r4[g][u], m4);
               }
             const float m0 = m01[0], m1 = m01[1], m2 = m23[0], m3 = m23[1];
-            const float gterm = (m2 - m0 * m0) / (m0 + 1e-12f);
+            const float gterm = div_nr(m2 - m0 * m0, m0 + 1e-12f);
             const float mx = ix * m0, my = iy * m1;
             const float vx = ix * ix * m2 - mx * mx, vy = iy * iy * m3 - my * my;
             const float cov = ix * iy * m4 - mx * my;
-            const float tt = wc * ((2.f * mx * my + 1e-6f) / (mx * mx + my * my + 1e-6f));
-            const float ss = wc * ((2.f * cov + 1e-6f) / (vx + vy + 1e-6f));
+            const float tt = wc * div_nr(2.f * mx * my + 1e-6f, mx * mx + my * my + 1e-6f);
+            const float ss = wc * div_nr(2.f * cov + 1e-6f, vx + vy + 1e-6f);
             const float gs = wave_sum(gterm), ts = wave_sum(tt), sss = wave_sum(ss);
             if (lane == rr - (kWin - 1)) {
               acc_g += gs;
@@ -422,12 +430,12 @@ __global__ __launch_bounds__(256, 2) void adists_window_planar_kernel(
                 m4 = fmaf(wv, r4[g][u], m4);
               }
             const float m0 = m01[0], m1 = m01[1], m2 = m23[0], m3 = m23[1];
-            const float gterm = (m2 - m0 * m0) / (m0 + 1e-12f);
+            const float gterm = div_nr(m2 - m0 * m0, m0 + 1e-12f);
             const float mx = ix * m0, my = iy * m1;
             const float vx = ix * ix * m2 - mx * mx, vy = iy * iy * m3 - my * my;
             const float cov = ix * iy * m4 - mx * my;
-            const float tt = wc * ((2.f * mx * my + 1e-6f) / (mx * mx + my * my + 1e-6f));
-            const float ss = wc * ((2.f * cov + 1e-6f) / (vx + vy + 1e-6f));
+            const float tt = wc * div_nr(2.f * mx * my + 1e-6f, mx * mx + my * my + 1e-6f);
+            const float ss = wc * div_nr(2.f * cov + 1e-6f, vx + vy + 1e-6f);
             if (live) {
               const size_t o = o0 + (size_t)(rr - (kWin - 1)) * Wo;
               if (c == 0) {
