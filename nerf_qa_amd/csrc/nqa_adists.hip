@@ -205,12 +205,6 @@ __global__ __launch_bounds__(256) void adists_weights_kernel(const float *__rest
 // T, S and the gamma term follow per lane; a 64-lane butterfly sums them over channels and the
 // total is banked in the accumulator of lane (row - strip start), so the strip's three output
 // columns leave as plain stores after the last channel block: no atomics, deterministic.
-// g2[t] = gaussian[t mod 21], t < 42: the doubled table the ring's vertical taps index with a moving origin
-__global__ void gauss2_fill_kernel(Gauss gw, float *__restrict__ g2) {
-  const int t = threadIdx.x;
-  if (t < 2 * kWin) g2[t] = gw.g[t % kWin];
-}
-
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 // a / b to ~1.5 ulp from v_rcp_f32 and one Newton step: 4 instructions where the IEEE sequence is ~10.
@@ -243,7 +237,7 @@ template <typename P, int C>  // C (64..512) is a template parameter so tap stri
 __global__ __launch_bounds__(256, 2) void adists_window_lanes_kernel(
     const typename P::T *__restrict__ fx, const typename P::T *__restrict__ fy, int H, int W,
     const float *__restrict__ q, int B, int ctot, int coff, const float *__restrict__ wgt, Gauss gw,
-    const float *__restrict__ g2, float *__restrict__ gamma, float *__restrict__ tw, float *__restrict__ sw) {
+    float *__restrict__ gamma, float *__restrict__ tw, float *__restrict__ sw) {
   typedef typename P::T T;
   // the wave index as a provably uniform value, so the row pointers and loop bounds stay scalar
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -261,9 +255,8 @@ __global__ __launch_bounds__(256, 2) void adists_window_lanes_kernel(
     const float ix = q[0 * st + qo + c], iy = q[1 * st + qo + c], wc = wgt[qo + c];
     const T *px = fx + ((size_t)(b * H + oy0) * W + ox) * C + cb;  // wave-uniform; the lane is added per load
     const T *py = fy + ((size_t)(b * H + oy0) * W + ox) * C + cb;
-    // ring of the last 21 rows' horizontal sums, slot = grp*7 + sub.  The row loop is unrolled by 7
-    // so `sub` is a compile-time index; `grp` (0..2) is dynamic and resolved by wave-uniform selects
-    // (a switch over 21 slots makes hipcc shuttle the whole ring through AGPRs every row).
+    // ring of the last 21 rows' horizontal sums, slot = grp*7 + sub (a dynamically indexed ring -- a switch
+    // over 21 slots -- makes hipcc shuttle all of it through AGPRs every row, so the row loop is unrolled).
     // The five running sums travel as two float pairs + one float so that the 2 x 21 taps per
     // (pixel, channel) are packed v_pk_fma_f32 / v_pk_mul_f32: 4 + 3 instructions per tap pair.
     f32x2 r01[3][7], r23[3][7];
@@ -275,11 +268,15 @@ __global__ __launch_bounds__(256, 2) void adists_window_lanes_kernel(
         r01[g][u] = r23[g][u] = (f32x2){0.f, 0.f};
         r4[g][u] = 0.f;
       }
-    int grp = 0;
-    for (int rr0 = 0; rr0 < nrows; rr0 += 7) {
+    // 21 rows per trip, fully unrolled: the ring slot (grp*7 + sub) of every row body is a compile-time
+    // constant, so a row's sums drop into their slot without selects and the vertical tap weights are
+    // immediates of the kernel-argument window (no table loads)
+    for (int rr0 = 0; rr0 < nrows; rr0 += 21) {
+#pragma unroll
+      for (int grp = 0; grp < 3; ++grp)
 #pragma unroll
       for (int sub = 0; sub < 7; ++sub) {
-        const int rr = rr0 + sub;
+        const int rr = rr0 + grp * 7 + sub;
         if (rr < nrows) {
           // all 42 loads go out back to back before any arithmetic (left to itself hipcc pairs each
           // load with its use and pays the memory latency 21 times per row)
@@ -302,22 +299,17 @@ __global__ __launch_bounds__(256, 2) void adists_window_lanes_kernel(
             h23 = gv * v + h23;
             h4 = fmaf(gv[0], v[1], h4);
           }
-#pragma unroll
-          for (int g = 0; g < 3; ++g) {
-            const bool hit = grp == g;
-            r01[g][sub] = hit ? h01 : r01[g][sub];
-            r23[g][sub] = hit ? h23 : r23[g][sub];
-            r4[g][sub] = hit ? h4 : r4[g][sub];
-          }
+          r01[grp][sub] = h01;
+          r23[grp][sub] = h23;
+          r4[grp][sub] = h4;
           if (rr >= kWin - 1) {
-            const float *gv = g2 + (kWin - 1 - (grp * 7 + sub));  // weight of ring slot s at this phase
             f32x2 m01 = {0.f, 0.f}, m23 = {0.f, 0.f};
             float m4 = 0.f;
 #pragma unroll
             for (int g = 0; g < 3; ++g)
 #pragma unroll
               for (int u = 0; u < 7; ++u) {
-                const float wv = gv[g * 7 + u];
+                const float wv = gw.g[(kWin - 1 - (grp * 7 + sub) + g * 7 + u) % kWin];  // slot (g,u) at this phase
                 m01 = wv * r01[g][u] + m01;
                 m23 = wv * r23[g][u] + m23;
                 m4 = fmaf(wv, r4[g][u], m4);
@@ -338,7 +330,6 @@ __global__ __launch_bounds__(256, 2) void adists_window_lanes_kernel(
           }
         }
       }
-      grp = grp == 2 ? 0 : grp + 1;
     }
   }
   if (lane < nout) {
@@ -356,8 +347,8 @@ __global__ __launch_bounds__(256, 2) void adists_window_lanes_kernel(
 // maps one after the other by the same lane (plain read-modify-write, no atomics).
 __global__ __launch_bounds__(256, 2) void adists_window_planar_kernel(
     const float *__restrict__ x, const float *__restrict__ y, int H, int W, const float *__restrict__ q, int B,
-    int ctot, int coff, const float *__restrict__ wgt, Gauss gw, const float *__restrict__ g2,
-    float *__restrict__ gamma, float *__restrict__ tw, float *__restrict__ sw) {
+    int ctot, int coff, const float *__restrict__ wgt, Gauss gw, float *__restrict__ gamma, float *__restrict__ tw,
+    float *__restrict__ sw) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.z;
   const int Ho = H - (kWin - 1), Wo = W - (kWin - 1);
@@ -384,11 +375,15 @@ __global__ __launch_bounds__(256, 2) void adists_window_planar_kernel(
         r01[g][u] = r23[g][u] = (f32x2){0.f, 0.f};
         r4[g][u] = 0.f;
       }
-    int grp = 0;
-    for (int rr0 = 0; rr0 < nrows; rr0 += 7) {
+    // 21 rows per trip, fully unrolled: the ring slot (grp*7 + sub) of every row body is a compile-time
+    // constant, so a row's sums drop into their slot without selects and the vertical tap weights are
+    // immediates of the kernel-argument window (no table loads)
+    for (int rr0 = 0; rr0 < nrows; rr0 += 21) {
+#pragma unroll
+      for (int grp = 0; grp < 3; ++grp)
 #pragma unroll
       for (int sub = 0; sub < 7; ++sub) {
-        const int rr = rr0 + sub;
+        const int rr = rr0 + grp * 7 + sub;
         if (rr < nrows) {
           float xr[kWin], yr[kWin];
 #pragma unroll
@@ -409,22 +404,17 @@ __global__ __launch_bounds__(256, 2) void adists_window_planar_kernel(
             h23 = gv * v + h23;
             h4 = fmaf(gv[0], v[1], h4);
           }
-#pragma unroll
-          for (int g = 0; g < 3; ++g) {
-            const bool hit = grp == g;
-            r01[g][sub] = hit ? h01 : r01[g][sub];
-            r23[g][sub] = hit ? h23 : r23[g][sub];
-            r4[g][sub] = hit ? h4 : r4[g][sub];
-          }
+          r01[grp][sub] = h01;
+          r23[grp][sub] = h23;
+          r4[grp][sub] = h4;
           if (rr >= kWin - 1) {
-            const float *gv = g2 + (kWin - 1 - (grp * 7 + sub));
             f32x2 m01 = {0.f, 0.f}, m23 = {0.f, 0.f};
             float m4 = 0.f;
 #pragma unroll
             for (int g = 0; g < 3; ++g)
 #pragma unroll
               for (int u = 0; u < 7; ++u) {
-                const float wv = gv[g * 7 + u];
+                const float wv = gw.g[(kWin - 1 - (grp * 7 + sub) + g * 7 + u) % kWin];  // slot (g,u) at this phase
                 m01 = wv * r01[g][u] + m01;
                 m23 = wv * r23[g][u] + m23;
                 m4 = fmaf(wv, r4[g][u], m4);
@@ -452,7 +442,6 @@ __global__ __launch_bounds__(256, 2) void adists_window_planar_kernel(
           }
         }
       }
-      grp = grp == 2 ? 0 : grp + 1;
     }
   }
 }
@@ -727,7 +716,7 @@ static Gauss make_gauss() {
 
 struct APlan {
   // byte offsets into the workspace
-  size_t bufA, bufB, taps[5], img4x, img4y, part, q, ent, wgt, maps[NQA_NUM_TAPS][4], acc, g2, total;
+  size_t bufA, bufB, taps[5], img4x, img4y, part, q, ent, wgt, maps[NQA_NUM_TAPS][4], acc, total;
   StageDesc sd;
   EntDesc ed;
   int h[NQA_NUM_TAPS], w[NQA_NUM_TAPS], c[NQA_NUM_TAPS];  // feature dims per tap (k=0 raw image)
@@ -813,7 +802,6 @@ static APlan make_plan(int B, int H, int W, int prec) {
     for (int j = 0; j < 4; ++j) p.maps[k][j] = take((size_t)B * p.mh[k] * p.mw[k] * 4);
   }
   p.acc = take((size_t)6 * B * sizeof(ChainAcc));
-  p.g2 = take(42 * sizeof(float));
   p.total = off;
   return p;
 }
@@ -829,28 +817,27 @@ static int launch_entropy(const void *feat, int B, int HW, int C, int ppb, const
 }
 
 static int launch_window_planar(const float *x, const float *y, int B, int H, int W, const float *q, int ctot, int coff,
-                                const float *wgt, const Gauss &g, const float *g2, float *gamma, float *tw, float *sw,
-                                hipStream_t st) {
+                                const float *wgt, const Gauss &g, float *gamma, float *tw, float *sw, hipStream_t st) {
   const int Ho = H - (kWin - 1), Wo = W - (kWin - 1);
   dim3 grid(cdiv(Wo, 256), cdiv(Ho, 64), B);
   TimedLaunch t(NQA_K_ADISTS, st);
-  adists_window_planar_kernel<<<grid, 256, 0, st>>>(x, y, H, W, q, B, ctot, coff, wgt, g, g2, gamma, tw, sw);
+  adists_window_planar_kernel<<<grid, 256, 0, st>>>(x, y, H, W, q, B, ctot, coff, wgt, g, gamma, tw, sw);
   return check_launch("adists_window_planar");
 }
 
 template <typename P>
 static int launch_window_lanes(const void *fx, const void *fy, int B, int H, int W, int C, const float *q, int ctot,
-                               int coff, const float *wgt, const Gauss &g, const float *g2, float *gamma, float *tw,
-                               float *sw, hipStream_t st) {
+                               int coff, const float *wgt, const Gauss &g, float *gamma, float *tw, float *sw,
+                               hipStream_t st) {
   const int Ho = H - (kWin - 1), Wo = W - (kWin - 1);
   dim3 grid(cdiv(Wo, 4), cdiv(Ho, 64), B);
   TimedLaunch t(NQA_K_ADISTS, st);
   const typename P::T *px = reinterpret_cast<const typename P::T *>(fx), *py = reinterpret_cast<const typename P::T *>(fy);
   switch (C) {
-    case 64: adists_window_lanes_kernel<P, 64><<<grid, 256, 0, st>>>(px, py, H, W, q, B, ctot, coff, wgt, g, g2, gamma, tw, sw); break;
-    case 128: adists_window_lanes_kernel<P, 128><<<grid, 256, 0, st>>>(px, py, H, W, q, B, ctot, coff, wgt, g, g2, gamma, tw, sw); break;
-    case 256: adists_window_lanes_kernel<P, 256><<<grid, 256, 0, st>>>(px, py, H, W, q, B, ctot, coff, wgt, g, g2, gamma, tw, sw); break;
-    case 512: adists_window_lanes_kernel<P, 512><<<grid, 256, 0, st>>>(px, py, H, W, q, B, ctot, coff, wgt, g, g2, gamma, tw, sw); break;
+    case 64: adists_window_lanes_kernel<P, 64><<<grid, 256, 0, st>>>(px, py, H, W, q, B, ctot, coff, wgt, g, gamma, tw, sw); break;
+    case 128: adists_window_lanes_kernel<P, 128><<<grid, 256, 0, st>>>(px, py, H, W, q, B, ctot, coff, wgt, g, gamma, tw, sw); break;
+    case 256: adists_window_lanes_kernel<P, 256><<<grid, 256, 0, st>>>(px, py, H, W, q, B, ctot, coff, wgt, g, gamma, tw, sw); break;
+    case 512: adists_window_lanes_kernel<P, 512><<<grid, 256, 0, st>>>(px, py, H, W, q, B, ctot, coff, wgt, g, gamma, tw, sw); break;
     default: set_error("adists_window_lanes: unsupported channel count %d", C); return NQA_E_SHAPE;
   }
   return check_launch("adists_window_lanes");
@@ -975,15 +962,6 @@ static int adists_run(const float *x, const float *y, int B, int H, int W, const
   }
   // ---- heavy pass: gamma / TW / SW maps per stage ----
   static const Gauss gauss = make_gauss();
-  float *g2 = reinterpret_cast<float *>(base + p.g2);
-  {
-    // the doubled window table the ring reads with a moving origin, written by the device from the
-    // kernel-argument copy of the window (stream-ordered; a host-to-device copy from pageable memory
-    // here would make every call wait for the stream)
-    TimedLaunch t(NQA_K_ADISTS, st);
-    gauss2_fill_kernel<<<1, 64, 0, st>>>(gauss, g2);
-    if ((rc = check_launch("gauss2_fill"))) return rc;
-  }
   for (int k = 0; k < 6; ++k) {
     float *gamma = reinterpret_cast<float *>(base + p.maps[k][0]);
     float *tw = reinterpret_cast<float *>(base + p.maps[k][1]);
@@ -995,14 +973,14 @@ static int adists_run(const float *x, const float *y, int B, int H, int W, const
       continue;
     }
     if (k == 0) {
-      rc = launch_window_planar(x, y, B, H, W, q, ctot, 0, wgt, gauss, g2, gamma, tw, sw, st);
+      rc = launch_window_planar(x, y, B, H, W, q, ctot, 0, wgt, gauss, gamma, tw, sw, st);
     } else {
       const char *tx = static_cast<const char *>(taps[k - 1]);
       const char *ty = tx + (size_t)B * p.h[k] * p.w[k] * p.c[k] * esz;
       switch (storage_prec(prec)) {
-        case NQA_PREC_F32: rc = launch_window_lanes<PrecF32>(tx, ty, B, p.h[k], p.w[k], p.c[k], q, ctot, p.sd.coff[k], wgt, gauss, g2, gamma, tw, sw, st); break;
-        case NQA_PREC_BF16: rc = launch_window_lanes<PrecBF16>(tx, ty, B, p.h[k], p.w[k], p.c[k], q, ctot, p.sd.coff[k], wgt, gauss, g2, gamma, tw, sw, st); break;
-        default: rc = launch_window_lanes<PrecF16>(tx, ty, B, p.h[k], p.w[k], p.c[k], q, ctot, p.sd.coff[k], wgt, gauss, g2, gamma, tw, sw, st); break;
+        case NQA_PREC_F32: rc = launch_window_lanes<PrecF32>(tx, ty, B, p.h[k], p.w[k], p.c[k], q, ctot, p.sd.coff[k], wgt, gauss, gamma, tw, sw, st); break;
+        case NQA_PREC_BF16: rc = launch_window_lanes<PrecBF16>(tx, ty, B, p.h[k], p.w[k], p.c[k], q, ctot, p.sd.coff[k], wgt, gauss, gamma, tw, sw, st); break;
+        default: rc = launch_window_lanes<PrecF16>(tx, ty, B, p.h[k], p.w[k], p.c[k], q, ctot, p.sd.coff[k], wgt, gauss, gamma, tw, sw, st); break;
       }
     }
     if (rc) return rc;
