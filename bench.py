@@ -167,7 +167,7 @@ def main():
             model.precision, model.vgg_source = net.precision, net.vgg_source
         else:
             model = DISTS(precision=args.precision).to(dev).eval()
-    prec = model.precision
+    prec = model.precision_for(H, W) if hasattr(model, "precision_for") else model.precision
 
     # synthetic frames generated on the device (no host I/O in the timed region); each rank
     # seeds with its rank so shards differ

@@ -28,7 +28,9 @@ def models(dev):
         m = {"f16": DISTS(precision="f16").to(dev).eval(), "f32": DISTS(precision="f32").to(dev).eval(),
              "a16": ADISTS(precision="f16").to(dev).eval(), "a32": ADISTS(precision="f32").to(dev).eval(),
              "a32s": ADISTS(precision="f32s").to(dev).eval(), "f32s": DISTS(precision="f32s").to(dev).eval()}
-        assert DISTS().precision == "f16" and ADISTS().precision == "f32s"  # the shipped defaults
+        d = DISTS()  # the shipped defaults: f16 convolutions from 96x96 pixels up, f32s below; A-DISTS always f32s
+        assert d.precision == "auto" and d.precision_for(256, 256) == "f16" and d.precision_for(64, 64) == "f32s"
+        assert ADISTS().precision == "f32s"
         return m
 
 

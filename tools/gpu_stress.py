@@ -1,0 +1,44 @@
+"""One-off randomized stress: many random frame sizes through both metrics against the CPU oracle, with a fenced
+workspace (prints the worst deviations; exits non-zero on a parity or fence failure)."""
+import sys, warnings
+import numpy as np
+import torch
+sys.path.insert(0, __file__.rsplit("/", 2)[0])
+sys.path.insert(0, __file__.rsplit("/", 2)[0] + "/tests")
+from nerf_qa_amd import ops, synth  # noqa: E402
+from nerf_qa_amd.ADISTS import ADISTS  # noqa: E402
+from nerf_qa_amd.DISTS_pytorch import DISTS  # noqa: E402
+from oracle import adists_oracle, dists_oracle  # noqa: E402
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+dev = torch.device("cuda:0")
+torch.set_num_threads(16)
+with warnings.catch_warnings():
+    warnings.simplefilter("ignore")
+    m16, m32s, a = DISTS(precision="f16").to(dev).eval(), DISTS(precision="f32s").to(dev).eval(), ADISTS().to(dev).eval()
+convs = dists_oracle.convs_from_numpy(synth.vgg16_weights(1234))
+rng = np.random.default_rng(99)
+worst = {"f16": 0.0, "f32s": 0.0, "a32s": 0.0}
+flips = 0
+for i in range(N):
+    h, w, b = int(rng.integers(1, 161)), int(rng.integers(1, 161)), int(rng.integers(1, 4))
+    kinds = [synth.KINDS[int(k)] for k in rng.integers(0, 4, b)]
+    xn, yn = synth.frame_batch([int(s) for s in rng.integers(0, 10 ** 6, b)], h, w, kinds)
+    x, y = torch.from_numpy(xn), torch.from_numpy(yn)
+    with torch.no_grad():
+        ref = dists_oracle.dists(x, y, convs, m16.alpha.detach().cpu(), m16.beta.detach().cpu())
+        aref = adists_oracle.adists(x, y, convs)
+        xd, yd = x.to(dev), y.to(dev)
+        e16 = (m16(xd, yd).cpu() - ref).abs().max().item()
+        e32 = (m32s(xd, yd).cpu() - ref).abs().max().item()
+        ga = a(xd, yd, as_loss=False).cpu()
+    ok = ~torch.isnan(aref)
+    assert torch.equal(torch.isnan(ga), torch.isnan(aref)), (h, w, b, ga, aref)
+    ea = (ga[ok] - aref[ok]).abs().max().item() if ok.any() else 0.0
+    if ea > 1e-4:
+        flips += 1
+        print(f"  A-DISTS knife edge? {h}x{w} b={b} kinds={kinds}: |d|={ea:.2e}", flush=True)
+    assert e16 <= 1e-4 and e32 <= 5e-6, (h, w, b, e16, e32)
+    worst = {"f16": max(worst["f16"], e16), "f32s": max(worst["f32s"], e32), "a32s": max(worst["a32s"], ea)}
+    if i % 25 == 24:
+        print(i + 1, worst, flush=True)
+print("done", N, worst, "A-DISTS cases above 1e-4:", flips)
