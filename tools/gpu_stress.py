@@ -12,6 +12,7 @@ from oracle import adists_oracle, dists_oracle  # noqa: E402
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 HI = int(sys.argv[2]) if len(sys.argv) > 2 else 160
 LO = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+BMAX = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 dev = torch.device("cuda:0")
 torch.set_num_threads(16)
 with warnings.catch_warnings():
@@ -22,7 +23,7 @@ rng = np.random.default_rng(99)
 worst = {"f16": 0.0, "f32s": 0.0, "a32s": 0.0}
 flips = 0
 for i in range(N):
-    h, w, b = int(rng.integers(LO, HI + 1)), int(rng.integers(LO, HI + 1)), int(rng.integers(1, 4))
+    h, w, b = int(rng.integers(LO, HI + 1)), int(rng.integers(LO, HI + 1)), int(rng.integers(1, BMAX + 1))
     kinds = [synth.KINDS[int(k)] for k in rng.integers(0, 4, b)]
     xn, yn = synth.frame_batch([int(s) for s in rng.integers(0, 10 ** 6, b)], h, w, kinds)
     x, y = torch.from_numpy(xn), torch.from_numpy(yn)
