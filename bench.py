@@ -1,18 +1,30 @@
 #!/usr/bin/env python3
-"""DISTS frame-pairs/s on MI355X (BASELINE.json metric), one process per GPU.
+"""DISTS / A-DISTS frame-pairs/s on MI355X (BASELINE.json metric), one process per GPU.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 256|1080p] [--precision f16]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 1080p|256|adists1080p|adists256|video10k]
+                  [--precision f16|f32s|f32|bf16] [--only]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A step is one DISTS.forward over one batch of synthetic frame pairs that are already
-resident in HBM (default workload = BASELINE.json configs[1]: 32 pairs of 256x256 per GPU).
-Frames shard across ranks with no data-path collective; the only exchange is one
-all-gather of the per-frame scores after the last step (inside the timed region).  Rank 0
-prints ONE JSON line.  The `roofline` object is for the dominant kernel (the MFMA
-implicit-GEMM conv3x3): algorithmic FLOPs of layers 1..12 per step / the HIP-event time of
-those launches, measured inside the timed region.  `cpu_baseline` times the CPU oracle
-(the reference's arithmetic, bit-identical to it in the authoring container) on a bounded
-sample on this box's host cores.
+The line's `value` is the headline workload, BASELINE.json configs[2]: B=8 pairs of 1920x1080 per GPU per
+step through DISTS.forward in its shipped precision (f16 MFMA convolutions), frames resident in HBM.  Frames
+shard across ranks with no data-path collective; the only exchange is ONE all-gather of the per-frame scores
+after the last step (inside the timed region) -- weak scaling, K steps of 8 pairs on every GPU.
+
+At N=1 the same JSON line also carries, under "workloads", the rest of the metric ("1080p & 256^2", DISTS
+and A-DISTS) measured the same way in the same process: 1080p in f32s (float32 activations, split-f16
+products: the reference's own precision class), 256x256 B=32 (configs[1]) in f16 and f32s, and A-DISTS at
+1080p B=8 (configs[4], f32s).  Every entry has its own `roofline` (the MFMA implicit-GEMM conv stack:
+algorithmic FLOPs of layers 1..12 / the HIP-event time of those launches, measured inside the timed region
+on the launch stream; `peak` is always the guide's dense 2.5 PFLOP/s f16 figure, and for f32s -- three f16
+MFMAs per algorithmic product -- both the algorithmic and the issued-MFMA fraction are given) and
+`roofline_hbm` (the HBM-bound L2-pool + statistics pass).  `roofline.traffic` comes from the committed
+rocprofv3 PMC summary of this same command (profiles/r02_traffic.json), per launch.
+
+`--workload video10k` is BASELINE.json configs[3]: a 10 000-frame 1080p video whose frames are generated on
+the device per batch from seed = frame index, sharded over the ranks (strong scaling), one all-gather.
+
+`cpu_baseline` times the CPU oracle (the reference's arithmetic, bit-identical to it in the authoring
+container) on a bounded sample of the headline workload on this box's host cores.
 """
 import argparse
 import json
@@ -20,7 +32,6 @@ import os
 import statistics
 import sys
 import time
-import warnings
 
 import torch
 import torch.distributed as dist
@@ -28,19 +39,27 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from nerf_qa_amd import ops, sharding, synth  # noqa: E402
+from nerf_qa_amd import ops, sharding, synth, video  # noqa: E402
+from nerf_qa_amd.ADISTS import ADISTS  # noqa: E402
 from nerf_qa_amd.DISTS_pytorch import DISTS  # noqa: E402
 
+VGG = "synth:1234"  # no ImageNet checkpoint offline: the deterministic stand-in weights, asked for explicitly
 WORKLOADS = {
-    "256": dict(name="configs[1]: B=32 256x256 synthetic frame pairs per GPU", B=32, H=256, W=256, metric="DISTS"),
     "1080p": dict(name="configs[2]: B=8 1920x1080 synthetic frame pairs per GPU", B=8, H=1080, W=1920, metric="DISTS"),
+    "256": dict(name="configs[1]: B=32 256x256 synthetic frame pairs per GPU", B=32, H=256, W=256, metric="DISTS"),
     "adists1080p": dict(name="configs[4]: A-DISTS, B=8 1920x1080 synthetic frame pairs per GPU", B=8, H=1080, W=1920,
                         metric="A-DISTS"),
     "adists256": dict(name="A-DISTS, B=32 256x256 synthetic frame pairs per GPU", B=32, H=256, W=256,
                       metric="A-DISTS"),
+    "video10k": dict(name="configs[3]: 10k-frame 1920x1080 synthetic video, frames generated on the device from "
+                          "seed = frame index, sharded over the ranks", B=8, H=1080, W=1920, metric="DISTS"),
 }
-PEAK_TFLOPS = {"f16": 2500.0, "bf16": 2500.0, "f32": 157.3,  # dense MFMA, MI355X_MICROARCH.md
-               "f32s": 2500.0 / 3}  # split-f16: three half MFMAs per algorithmic product
+# what the N=1 line measures beside the headline (workload key, precision)
+COMPANIONS = (("1080p", "f32s"), ("256", "f16"), ("256", "f32s"), ("adists1080p", "f32s"))
+PEAK_F16_TFLOPS = 2500.0  # dense f16/bf16 MFMA, MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3   # exact-f32 MFMA
+PEAK_HBM_GBS = 8000.0
+MFMA_PER_PRODUCT = {"f16": 1, "bf16": 1, "f32s": 3, "f32": 1}
 
 
 def conv_flops_per_image(h, w):
@@ -65,14 +84,46 @@ def pool_bytes_per_image(h, w, esz):
     return total
 
 
-def hbm_roofline(launches_ms, h, w, b, steps, prec):
-    """Secondary roofline object: the HBM-bound pool+statistics kernel (algorithmic bytes / HIP-event time)."""
-    n, ms = launches_ms
+def load_traffic():
+    """Committed PMC summary (rocprofv3 --pmc passes of this command, corrected as MI355X_MICROARCH.md's HBM
+    section prescribes: FETCH_SIZE doubled on gfx950): {workload/prec: {"conv": bytes per launch, "pool": ...}}."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+    except (OSError, ValueError):
+        return {}
+
+
+def rooflines(ktimes, h, w, b, prec, traffic):
+    """roofline (MFMA conv stack) and roofline_hbm (pool+statistics) from the HIP-event times of one timed run."""
+    ig_flops, _ = conv_flops_per_image(h, w)
+    n_ig, ms_ig = ktimes["conv_igemm"]
+    per_step = 12  # launches of class conv_igemm per step: layers 1..12 (16-bit modes: fused stage 1 + layers 2..12)
+    steps = n_ig / per_step if n_ig else 0
+    ach = ig_flops * 2 * b * steps / (ms_ig * 1e-3) / 1e12 if ms_ig > 0 else None
+    peak = PEAK_F32_TFLOPS if prec == "f32" else PEAK_F16_TFLOPS
+    roof = {
+        "kernel": "conv3x3_igemm_kernel + conv1_fused_kernel (VGG layers 1..12, MFMA implicit GEMM)",
+        "bound": "mfma", "achieved": round(ach, 2) if ach else None, "peak": peak, "unit": "TFLOP/s",
+        "frac": round(ach / peak, 4) if ach else None,
+        "traffic": traffic.get("conv"), "launches": n_ig, "avg_launch_ms": round(ms_ig / n_ig, 5) if n_ig else None,
+        "flop_per_launch_avg": round(ig_flops * 2 * b / per_step),
+        "note": "achieved = algorithmic FLOPs / HIP-event time; peak = dense f16 MFMA (2.5 PF)" if prec != "f32" else
+                "exact-f32 MFMA; peak = 157.3 TF",
+    }
+    if prec == "f32s" and ach:
+        roof["mfma_issued_tflops"] = round(3 * ach, 1)
+        roof["frac_of_issued_mfma"] = round(3 * ach / peak, 4)
+        roof["note"] = ("f32s issues three f16 MFMAs per algorithmic product (hi*hi + hi*lo + lo*hi): `frac` is "
+                        "algorithmic FLOP/s over the 2.5 PF f16 peak, `frac_of_issued_mfma` is the matrix cores' load")
+    n_p, ms_p = ktimes["l2pool"]
     esz = 2 if prec in ("f16", "bf16") else 4
-    ach = pool_bytes_per_image(h, w, esz) * 2 * b * steps / (ms * 1e-3) / 1e9 if ms > 0 else None
-    return {"kernel": "pool_stats_kernel (L2-pool + the five statistics sums of taps 1..4, one pass)", "bound": "hbm",
-            "achieved": round(ach, 1) if ach else None, "peak": 8000.0, "unit": "GB/s",
-            "frac": round(ach / 8000.0, 4) if ach else None, "traffic": None, "launches": n}
+    ach_b = pool_bytes_per_image(h, w, esz) * 2 * b * steps / (ms_p * 1e-3) / 1e9 if ms_p > 0 and steps else None
+    hbm = {"kernel": "pool_stats_kernel (L2-pool + the five statistics sums of taps 1..4, one pass)", "bound": "hbm",
+           "achieved": round(ach_b, 1) if ach_b else None, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+           "frac": round(ach_b / PEAK_HBM_GBS, 4) if ach_b else None, "traffic": traffic.get("pool"), "launches": n_p,
+           "bytes_per_launch_avg": round(pool_bytes_per_image(h, w, esz) * 2 * b / 4)}
+    kms = {k: round(v[1] / max(steps, 1), 4) for k, v in ktimes.items() if v[0]}
+    return roof, hbm, kms
 
 
 def host_cores():
@@ -88,7 +139,13 @@ def host_cores():
     return n
 
 
-def cpu_baseline(h, w, budget_s=20.0, adists=False):
+def DISTS_alpha_beta():
+    import numpy as np
+    d = np.load(os.path.join(ROOT, "nerf_qa_amd", "data", "dists_alpha_beta.npz"))
+    return torch.from_numpy(d["alpha"]).view(1, -1, 1, 1), torch.from_numpy(d["beta"]).view(1, -1, 1, 1)
+
+
+def cpu_baseline(h, w, budget_s=24.0, adists=False):
     """The oracle (kind "port") on the host cores: frame-pairs/s on a bounded sample."""
     from oracle import adists_oracle, dists_oracle
     cores = host_cores()
@@ -112,28 +169,110 @@ def cpu_baseline(h, w, budget_s=20.0, adists=False):
         t0 = time.perf_counter()
         run(x, y)
         times.append(time.perf_counter() - t0)
-        if sum(times) > budget_s:
+        if sum(times) + t_one > budget_s:
             break
     return {"value": round(n / statistics.median(times), 4), "unit": "frame-pairs/s", "cores": cores,
-            "kind": "port", "sample": f"{n} pair(s) of {h}x{w}, CPU oracle fp32, median of {len(times)} after 1 warm-up"}
+            "kind": "port", "sample": f"{n} pair(s) of {h}x{w}, CPU oracle fp32 ({'A-DISTS' if adists else 'DISTS'}), "
+                                      f"median of {len(times)} after 1 warm-up"}
 
 
-def DISTS_alpha_beta():
-    import numpy as np
-    d = np.load(os.path.join(ROOT, "nerf_qa_amd", "data", "dists_alpha_beta.npz"))
-    return torch.from_numpy(d["alpha"]).view(1, -1, 1, 1), torch.from_numpy(d["beta"]).view(1, -1, 1, 1)
+def make_model(metric, precision, dev, h, w):
+    """-> (callable(ref, render) -> (B,) scores, the precision mode it runs this frame size in, weight source)."""
+    if metric == "A-DISTS":
+        net = ADISTS(precision=precision, vgg16_path=VGG).to(dev).eval()
+        return (lambda a, b: net(a, b, as_loss=False)), net.precision, net.vgg_source  # x = reference frame
+    net = DISTS(precision=precision, vgg16_path=VGG).to(dev).eval()
+    return net, net.precision_for(h, w), net.vgg_source
+
+
+def synth_frames(b, h, w, dev, seed):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    x = torch.rand(b, 3, h, w, device=dev, generator=g)
+    y = (x + 0.1 * torch.randn(b, 3, h, w, device=dev, generator=g)).clamp_(0, 1)
+    return x, y
+
+
+def run_workload(key, precision, steps, warmup, dev, world, rank, batch=0):
+    """K timed steps of one workload on this rank; returns (dt max-over-ranks, scores, ktimes, prec, B, H, W, src)."""
+    wl = WORKLOADS[key]
+    B, H, W = batch or wl["B"], wl["H"], wl["W"]
+    model, prec, src = make_model(wl["metric"], precision, dev, H, W)
+    # synthetic frames generated on the device (no host I/O anywhere); each rank seeds with its rank so shards differ
+    x, y = synth_frames(B, H, W, dev, 1000 + rank)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    scores = torch.empty(steps * B, dtype=torch.float32, device=dev)
+    with torch.no_grad():
+        for _ in range(warmup):
+            model(x, y)
+        if world > 1:  # warm the collective too
+            sharding.gather_scores(scores, world * scores.numel())
+        sync()
+        ops.timing_enable(True)
+        t0 = time.perf_counter()
+        for k in range(steps):
+            scores[k * B:(k + 1) * B] = model(x, y)
+        all_scores = sharding.gather_scores(scores, world * scores.numel()) if world > 1 else scores
+        sync()
+        dt = time.perf_counter() - t0
+    ktimes = ops.timing_collect()
+    ops.timing_enable(False)
+    assert torch.isfinite(all_scores).all()
+    del x, y
+    return dt, ktimes, prec, B, H, W, src
+
+
+def run_video(n_frames, precision, warmup, dev, world, rank, batch):
+    """configs[3]: frames [0, n_frames) of a 1080p video, generated on the device per batch from seed = frame
+    index (no rank ever holds the video), contiguous frame ranges per rank, ONE all-gather of the scores."""
+    wl = WORKLOADS["video10k"]
+    H, W = wl["H"], wl["W"]
+    net, prec, src = make_model("DISTS", precision, dev, H, W)
+
+    def score_batch(lo, hi):
+        ref, ren = video.synthetic_frames(range(lo, hi), H, W, dev)
+        return net(ref, ren)
+
+    with torch.no_grad():
+        for _ in range(max(1, warmup)):
+            score_batch(0, batch)
+        if world > 1:
+            sharding.gather_scores(torch.zeros(-(-n_frames // world), device=dev), n_frames)
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        ops.timing_enable(True)
+        t0 = time.perf_counter()
+        scores = sharding.score_frames_sharded(score_batch, n_frames, batch, dev)
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+    ktimes = ops.timing_collect()
+    ops.timing_enable(False)
+    assert scores.numel() == n_frames and torch.isfinite(scores).all()
+    cols = video.video_columns("DISTS", scores.cpu().numpy())
+    return dt, ktimes, prec, H, W, src, {k: float(v) for k, v in cols.items()}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="256",
-                    help="256 (default, BASELINE configs[1]) | 1080p | adists1080p | adists256")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="1080p",
+                    help="1080p (default, BASELINE configs[2]) | 256 | adists1080p | adists256 | video10k")
     ap.add_argument("--precision", default=None, help="f16 (DISTS default), f32s (A-DISTS default), f32, bf16")
+    ap.add_argument("--only", action="store_true", help="skip the companion workloads of the N=1 line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=0, help="override pairs per GPU per step (experiments only)")
+    ap.add_argument("--frames", type=int, default=10000, help="frames of the video10k workload")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -156,61 +295,49 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    traffic = load_traffic()
     wl = WORKLOADS[args.workload]
-    B, H, W = args.batch or wl["B"], wl["H"], wl["W"]
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        if wl["metric"] == "A-DISTS":
-            from nerf_qa_amd.ADISTS import ADISTS
-            net = ADISTS(precision=args.precision).to(dev).eval()
-            model = lambda a, b: net(a, b, as_loss=False)  # noqa: E731  (x = reference frame drives ps / weights)
-            model.precision, model.vgg_source = net.precision, net.vgg_source
-        else:
-            model = DISTS(precision=args.precision).to(dev).eval()
-    prec = model.precision_for(H, W) if hasattr(model, "precision_for") else model.precision
 
-    # synthetic frames generated on the device (no host I/O in the timed region); each rank
-    # seeds with its rank so shards differ
-    g = torch.Generator(device=dev).manual_seed(1000 + rank)
-    x = torch.rand(B, 3, H, W, device=dev, generator=g)
-    y = (x + 0.1 * torch.randn(B, 3, H, W, device=dev, generator=g)).clamp_(0, 1)
-
-    def sync():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize(dev)
-
-    scores = torch.empty(args.steps * B, dtype=torch.float32, device=dev)
-    with torch.no_grad():
-        for _ in range(args.warmup):
-            model(x, y)
-        if world > 1:  # warm the collective too
-            sharding.gather_scores(scores, world * scores.numel())
-        sync()
-        ops.timing_enable(True)
-        t0 = time.perf_counter()
-        for k in range(args.steps):
-            scores[k * B:(k + 1) * B] = model(x, y)
-        all_scores = sharding.gather_scores(scores, world * scores.numel()) if world > 1 else scores
-        sync()
-        dt = time.perf_counter() - t0
-    ktimes = ops.timing_collect()
-    ops.timing_enable(False)
-
-    if world > 1:
+    def rank_times(dt):
+        """(max over ranks, per-rank list) of a rank's wall time."""
+        if world == 1:
+            return dt, [dt]
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
-    assert torch.isfinite(all_scores).all()
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        per = [float(v.item()) for v in allt]
+        return max(per), per
 
+    if args.workload == "video10k":
+        batch = args.batch or wl["B"]
+        dt, ktimes, prec, H, W, src, cols = run_video(args.frames, args.precision, args.warmup, dev, world, rank, batch)
+        dt, per = rank_times(dt)
+        if rank == 0:
+            roof, hbm, kms = rooflines(ktimes, H, W, batch, prec, traffic.get(f"1080p/{prec}", {}))
+            # this rank's launches cover its own shard only: per-launch figures stay valid, per-step ones are per batch
+            per_rank = -(-args.frames // world)
+            nsteps = max(1, -(-per_rank // batch))
+            out = {"metric": "DISTS frame-pairs/s", "value": round(args.frames / dt, 2), "unit": "frame-pairs/s",
+                   "n_gpus": world, "steps": nsteps, "warmup": max(1, args.warmup),
+                   "ms_per_step": round(dt / nsteps * 1e3, 4),
+                   "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": prec,
+                   "data": "synthetic",
+                   "config": {"workload": wl["name"], "frames": args.frames, "pairs_per_gpu_per_step": batch,
+                              "height": H, "width": W, "vgg_weights": src,
+                              "sharding": f"contiguous frame ranges over {world} ranks, one all-gather of scores"},
+                   "per_rank_pairs_per_s": [round(-(-args.frames // world) / t, 2) for t in per],
+                   "video_columns": cols, "roofline": roof, "kernel_ms_per_step": kms, "roofline_hbm": hbm}
+            print(json.dumps(out), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    dt, ktimes, prec, B, H, W, src = run_workload(args.workload, args.precision, args.steps, args.warmup, dev, world,
+                                                  rank, args.batch)
+    dt, per = rank_times(dt)
+    out = None
     if rank == 0:
-        ig_flops, c1_flops = conv_flops_per_image(H, W)
-        n_ig, ms_ig = ktimes["conv_igemm"]
-        launches_per_step = 12
-        steps_timed = n_ig / launches_per_step if n_ig else 0
-        achieved = (ig_flops * 2 * B * steps_timed) / (ms_ig * 1e-3) / 1e12 if ms_ig > 0 else None
-        peak = PEAK_TFLOPS[prec]
+        roof, hbm, kms = rooflines(ktimes, H, W, B, prec, traffic.get(f"{args.workload}/{prec}", {}))
         out = {
             "metric": wl["metric"] + " frame-pairs/s",
             "value": round(world * B * args.steps / dt, 2),
@@ -225,17 +352,26 @@ def main():
             "dtype": prec,
             "data": "synthetic",
             "config": {"workload": wl["name"], "pairs_per_gpu_per_step": B, "height": H, "width": W,
-                       "vgg_weights": model.vgg_source, "sharding": f"frames/{world} ranks, one all-gather of scores"},
-            "roofline": {
-                "kernel": "conv3x3_igemm_kernel (VGG layers 1..12, MFMA implicit GEMM)",
-                "bound": "mfma", "achieved": round(achieved, 2) if achieved else None, "peak": peak,
-                "unit": "TFLOP/s", "frac": round(achieved / peak, 4) if achieved else None, "traffic": None,
-                "launches": n_ig, "avg_launch_ms": round(ms_ig / n_ig, 5) if n_ig else None,
-                "flop_per_launch_avg": round(ig_flops * 2 * B / launches_per_step),
-            },
-            "kernel_ms_per_step": {k: round(v[1] / max(steps_timed, 1), 4) for k, v in ktimes.items() if v[0]},
-            "roofline_hbm": hbm_roofline(ktimes["l2pool"], H, W, B, steps_timed, prec),
+                       "vgg_weights": src, "sharding": f"frames/{world} ranks, one all-gather of scores",
+                       "timing": "hipEvent pairs around every kernel launch are recorded inside the timed region"},
+            "per_rank_pairs_per_s": [round(B * args.steps / t, 2) for t in per],
+            "roofline": roof,
+            "kernel_ms_per_step": kms,
+            "roofline_hbm": hbm,
         }
+    if world == 1 and not args.only and args.workload == "1080p" and not args.batch:
+        comp = {}
+        for key, cprec in COMPANIONS:
+            cdt, ckt, cp, cb, ch, cw, _ = run_workload(key, cprec, args.steps, args.warmup, dev, 1, 0)
+            croof, chbm, ckms = rooflines(ckt, ch, cw, cb, cp, traffic.get(f"{key}/{cp}", {}))
+            comp[f"{key}/{cp}"] = {"workload": WORKLOADS[key]["name"], "metric": WORKLOADS[key]["metric"] + " frame-pairs/s",
+                                   "value": round(cb * args.steps / cdt, 2), "unit": "frame-pairs/s",
+                                   "ms_per_step": round(cdt / args.steps * 1e3, 4), "dtype": cp,
+                                   "pairs_per_gpu_per_step": cb, "roofline": croof, "kernel_ms_per_step": ckms,
+                                   "roofline_hbm": chbm}
+            torch.cuda.empty_cache()
+        out["workloads"] = comp
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(H, W, adists=wl["metric"] == "A-DISTS")
         print(json.dumps(out), flush=True)

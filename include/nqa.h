@@ -15,8 +15,10 @@
  *     are enqueued on it and the call returns without synchronising;
  *   - return value: 0 on success, a negative NQA_E_* code on failure, with a
  *     message available from nqa_last_error() (thread-local);
- *   - no global mutable state besides the thread-local error string and the
- *     optional timing ring (nqa_timing_*), so calls are re-entrant per stream.
+ *   - the only mutable state is THREAD-LOCAL (the error string, the timing ring of nqa_timing_*
+ *     and the tuning choice of nqa_set_conv_variant) plus idempotent per-device caches (kernel
+ *     attributes, CU count), so calls are re-entrant per (thread, stream): one thread's tuning
+ *     or timing never changes or observes another thread's launches.
  *
  * Layouts
  *   - images enter as the reference's tensors: float32 NCHW, values in [0,1];
@@ -192,7 +194,8 @@ int nqa_resize_pil_bilinear_u8(const uint8_t *in, int n, int Hin, int Win, int H
  * + 8-wave 128 ch x 512 px tiles wherever the map is large enough (measured equal to 1).
  * Adding 4 selects the second form of the fused stage-1 kernel (an implicit-GEMM tile that computes
  * its conv1_1 halo itself instead of the persistent two-phase kernel; measured within +-6 %).  Results are identical in
- * every variant; this only exists so they can be timed against each other in one process. */
+ * every variant; this only exists so they can be timed against each other in one process.
+ * The choice is thread-local (it applies to the calling thread's later calls only). */
 int nqa_set_conv_variant(int variant);
 
 /* ---- per-kernel timing (bench.py's roofline leg) -------------------------------- */
@@ -200,7 +203,8 @@ int nqa_set_conv_variant(int variant);
 /* When enabled, every launch of the conv / pool / stats kernels is bracketed by a
  * pair of hipEvents recorded on the launch stream.  nqa_timing_collect synchronises
  * those events and returns, per kernel class, the number of launches and the summed
- * device time in milliseconds, then clears the ring. */
+ * device time in milliseconds, then clears the ring.  Thread-local: only the enabling thread's
+ * launches are bracketed, and it collects only its own. */
 enum { NQA_K_CONV1 = 0, NQA_K_CONV = 1, NQA_K_POOL = 2, NQA_K_STATS = 3, NQA_K_ADISTS = 4, NQA_K_PREP = 5, NQA_K_COUNT = 6 };
 int nqa_timing_enable(int on);
 int nqa_timing_collect(int launches[NQA_K_COUNT], double ms[NQA_K_COUNT]);

@@ -17,7 +17,9 @@ flip moves the score by a channel weight, ~5e-4 (measured; DISTS' statistics hav
 precision="f16" stays available as the opt-in fast mode (3x the throughput at 1080p).
 
 as_loss=True in the reference runs the pyramids WITH autograd (:139-141); this build has
-no VGG backward, so the value 1-mean(D) is returned without a graph.  as_map=True returns the
+no VGG backward, so when a gradient would actually be needed (grad mode on and x or y requires
+grad) the call raises NotImplementedError, like DISTS(require_grad=True); otherwise the value
+1-mean(D) is returned (there is no graph to lose).  as_map=True returns the
 reference's [B,B,H,W] distortion map (:163,188-193) from one extra kernel.
 """
 from __future__ import annotations
@@ -94,6 +96,10 @@ class ADISTS(torch.nn.Module):
 
     def forward(self, x, y, as_loss=True, as_map=False):
         assert x.shape == y.shape
+        if as_loss and torch.is_grad_enabled() and (x.requires_grad or y.requires_grad):
+            raise NotImplementedError("ADISTS(as_loss=True) on grad-requiring inputs needs a backward pass through "
+                                      "the VGG pyramid (ADISTS.py:139-141), which this build does not have; call it "
+                                      "under torch.no_grad() or with as_loss=False for the value")
         if as_map:
             # (:163,188-189,193) the reference's (B,H,W) + (B,1,H,W) addition broadcasts to (B,B,H,W)
             # with out[i, j] = map[i]; reproduced as is (callers use B = 1, nerf_nr_qa_prep_4.py:70)

@@ -5,7 +5,9 @@ Differences from the canonical module (reference file DISTS_pt_original.py):
     values are kept as original_alpha / original_beta (:67-68, read by model_stats.py:89);
   * forward applies optional relu / detach_beta / w_sum_detach from the run config (:111-119);
   * the result is `score.squeeze()` (:134): shape (B,) for B > 1 and 0-d for B == 1;
-  * project_weights uses the configured lower bound on every channel (:88-95).
+  * project_weights uses the configured lower bound on every channel (:88-95);
+  * prepare_image(image, resize=True) always keeps the aspect ratio (:140-144; imported by
+    run_nerf_qa.py:29 and nerf_qa/data_fr.py:34).
 The VGG pyramid and the statistics are the same HIP kernels; only the 2950-term weighted sum is
 evaluated in PyTorch so that autograd reaches alpha and beta.
 """
@@ -16,6 +18,7 @@ import torch
 
 from ..config import config
 from .DISTS_pt import _DATA, DISTS as _BaseDISTS
+from .DISTS_pt import prepare_image as _prepare_image
 
 
 class DISTS(_BaseDISTS):
@@ -68,3 +71,9 @@ class DISTS(_BaseDISTS):
             o += c
         score = 1 - (dist1 + dist2).squeeze()
         return score.mean() if batch_average else score
+
+
+def prepare_image(image, resize=True):
+    """PIL image -> float32 (1,3,H,W) in [0,1]; DISTS_pt_original.py:140-144: `resize(image, 256)` scales the
+    short side to 256 and keeps the aspect ratio (long side = int(256 * long / short))."""
+    return _prepare_image(image, resize=resize, keep_aspect_ratio=True)

@@ -1,7 +1,8 @@
 """Run configuration the reference reads from the global `wandb.config`.
 
 DISTS_pt_original / DISTS_pt_softmax / model_stats in the reference read options from
-`wandb.config` inside model code (DISTS_pt_original.py:69-70,111-119; model_stats.py:31-66).
+`wandb.config` inside model code (DISTS_pt_original.py:69-70,111-119; model_stats.py:31-66;
+model.py:26,40,52).
 If wandb is importable and a run is active, that object is used, so the reference's scripts keep
 working unchanged; otherwise this module-level namespace holds the same keys with the defaults
 of wandb/config-nerf-qa.yaml-style runs and can be edited by the caller.
@@ -17,6 +18,7 @@ _local = SimpleNamespace(
     detach_beta="False",
     regression_type="linear",     # linear | sqrt | logistic
     subjective_score_type="MOS",
+    mode="linear",                # nerf_qa/model.py:26,40,52: linear | sqrt | softmax | softmax+sqrt
 )
 
 

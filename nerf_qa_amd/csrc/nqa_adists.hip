@@ -21,6 +21,7 @@
 namespace nqa {
 
 static constexpr int kWin = 21;
+static constexpr int kChainBlocks = 1024;  // most blocks per image of the chain's reduction kernels
 
 struct Gauss {
   float g[kWin];
@@ -509,7 +510,33 @@ __global__ __launch_bounds__(256) void chain_init_kernel(ChainAcc *acc, int n) {
   }
 }
 
-__global__ __launch_bounds__(256) void chain_moments_kernel(const float *__restrict__ gamma, int n, ChainAcc *acc) {
+// Cross-block sums of the chain (gamma moments, the stage's D) are NOT accumulated with fp64 atomics: their
+// arrival order would make the last bits of a score differ from run to run.  Each block stores its partial
+// in a slot of its own and chain_fold_kernel adds the slots in a fixed order (min / max stay atomic: exact).
+__global__ __launch_bounds__(256) void chain_fold_kernel(const double *__restrict__ cp, int G, int nvals, int which,
+                                                         ChainAcc *acc) {
+  __shared__ double red[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int v = 0; v < nvals; ++v) {
+    double s = 0.0;
+    for (int g = tid; g < G; g += 256) s += cp[((size_t)b * G + g) * nvals + v];
+    __syncthreads();
+    red[tid] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if (tid < off) red[tid] += red[tid + off];
+      __syncthreads();
+    }
+    if (tid == 0) {
+      if (which == 1) acc[b].dsum = red[0];
+      else if (v == 0) acc[b].sum = red[0];
+      else acc[b].sumsq = red[0];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void chain_moments_kernel(const float *__restrict__ gamma, int n,
+                                                            double *__restrict__ cp /* [B][gridDim.x][2] */) {
   __shared__ double red[2][256];
   const int b = blockIdx.y, tid = threadIdx.x;
   double s = 0, s2 = 0;
@@ -529,8 +556,8 @@ __global__ __launch_bounds__(256) void chain_moments_kernel(const float *__restr
     __syncthreads();
   }
   if (tid == 0) {
-    atomicAdd(&acc[b].sum, red[0][0]);
-    atomicAdd(&acc[b].sumsq, red[1][0]);
+    cp[((size_t)b * gridDim.x + blockIdx.x) * 2 + 0] = red[0][0];
+    cp[((size_t)b * gridDim.x + blockIdx.x) * 2 + 1] = red[1][0];
   }
 }
 
@@ -605,7 +632,8 @@ __global__ __launch_bounds__(256) void chain_ppminmax_kernel(const float *__rest
 __global__ __launch_bounds__(256) void chain_final_kernel(const float *__restrict__ gamma, int h, int w,
                                                           const float *__restrict__ prev, int hp, int wp,
                                                           const float *__restrict__ tw, const float *__restrict__ sw,
-                                                          float *__restrict__ psprod, ChainAcc *acc) {
+                                                          float *__restrict__ psprod, const ChainAcc *acc,
+                                                          double *__restrict__ cp /* [B][gridDim.x] */) {
   __shared__ double red[256];
   const int b = blockIdx.y, n = h * w, tid = threadIdx.x;
   float mean, sd;
@@ -624,7 +652,7 @@ __global__ __launch_bounds__(256) void chain_final_kernel(const float *__restric
     if (tid < off) red[tid] += red[tid + off];
     __syncthreads();
   }
-  if (tid == 0) atomicAdd(&acc[b].dsum, red[0]);
+  if (tid == 0) cp[(size_t)b * gridDim.x + blockIdx.x] = red[0];
 }
 
 // global-branch stage: ps = sigmoid(gamma); ps_prod = ps * prev[0,0]; D = (1-ps_prod) TW + ps_prod SW
@@ -716,7 +744,7 @@ static Gauss make_gauss() {
 
 struct APlan {
   // byte offsets into the workspace
-  size_t bufA, bufB, taps[5], img4x, img4y, part, q, ent, wgt, maps[NQA_NUM_TAPS][4], acc, total;
+  size_t bufA, bufB, taps[5], img4x, img4y, part, q, ent, wgt, maps[NQA_NUM_TAPS][4], acc, chain_part, total;
   StageDesc sd;
   EntDesc ed;
   int h[NQA_NUM_TAPS], w[NQA_NUM_TAPS], c[NQA_NUM_TAPS];  // feature dims per tap (k=0 raw image)
@@ -802,6 +830,7 @@ static APlan make_plan(int B, int H, int W, int prec) {
     for (int j = 0; j < 4; ++j) p.maps[k][j] = take((size_t)B * p.mh[k] * p.mw[k] * 4);
   }
   p.acc = take((size_t)6 * B * sizeof(ChainAcc));
+  p.chain_part = take((size_t)B * kChainBlocks * 2 * sizeof(double));
   p.total = off;
   return p;
 }
@@ -1002,11 +1031,14 @@ static int adists_run(const float *x, const float *y, int B, int H, int W, const
       ChainAcc *a = acc + (size_t)k * B;
       if (p.windowed[k]) {
         const int n = p.mh[k] * p.mw[k];
-        dim3 grid(min(cdiv(n, 256), 1024), B);
-        chain_moments_kernel<<<grid, 256, 0, st>>>(gamma, n, a);
+        dim3 grid(min(cdiv(n, 256), kChainBlocks), B);
+        double *cp = reinterpret_cast<double *>(base + p.chain_part);
+        chain_moments_kernel<<<grid, 256, 0, st>>>(gamma, n, cp);
+        chain_fold_kernel<<<B, 256, 0, st>>>(cp, grid.x, 2, 0, a);
         chain_psminmax_kernel<<<grid, 256, 0, st>>>(gamma, n, a);
         chain_ppminmax_kernel<<<grid, 256, 0, st>>>(gamma, p.mh[k], p.mw[k], prev, hp, wp, a);
-        chain_final_kernel<<<grid, 256, 0, st>>>(gamma, p.mh[k], p.mw[k], prev, hp, wp, tw, sw, psprod, a);
+        chain_final_kernel<<<grid, 256, 0, st>>>(gamma, p.mh[k], p.mw[k], prev, hp, wp, tw, sw, psprod, a, cp);
+        chain_fold_kernel<<<B, 256, 0, st>>>(cp, grid.x, 1, 1, a);
       } else {
         chain_global_kernel<<<cdiv(B, 256), 256, 0, st>>>(gamma, prev, hp * wp, tw, sw, psprod, a, B);
       }

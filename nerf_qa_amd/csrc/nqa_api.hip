@@ -31,11 +31,14 @@ int check_launch(const char *what) {
 }
 
 // ---- timing ring ------------------------------------------------------------------
+// Thread-local like the error string: a thread that enables timing brackets ITS OWN launches (on whatever
+// streams it uses) and collects only those, so concurrent callers on other threads / streams are neither
+// timed nor disturbed.  The events are created once per thread and reused.
 static const int kRing = 16384;
-static bool g_timing = false;
-static std::vector<hipEvent_t> g_ev0, g_ev1;
-static std::vector<int> g_cls;
-static int g_used = 0;
+static thread_local bool g_timing = false;
+static thread_local std::vector<hipEvent_t> g_ev0, g_ev1;
+static thread_local std::vector<int> g_cls;
+static thread_local int g_used = 0;
 
 TimedLaunch::TimedLaunch(int kc, hipStream_t s) : kclass(kc), stream(s), slot(-1) {
   if (!g_timing || g_used >= kRing) return;
@@ -198,7 +201,7 @@ static bool bad_dims(const char *who, int n, int H, int W, int prec, int chan = 
     set_error("%s: unknown prec %d", who, prec);
     return true;
   }
-  if ((long)H * W * chan * (long)prec_elem_bytes(prec) >= (1L << 31)) {
+  if (chan > 0 && (long)H * W * chan * (long)prec_elem_bytes(prec) >= (1L << 31)) {
     set_error("%s: map too large for 32-bit in-image byte offsets (H*W*%d channels*%d bytes >= 2^31)", who, chan,
               (int)prec_elem_bytes(prec));
     return true;
@@ -413,7 +416,13 @@ int nqa_nhwc_to_nchw_f32(const void *in, int n, int H, int W, int C, int prec, f
     set_error("nhwc_to_nchw: null pointer");
     return NQA_E_ARG;
   }
-  if (bad_dims("nhwc_to_nchw", n, H, W, prec) || C <= 0) return NQA_E_ARG;
+  // the export kernel indexes with size_t: no 32-bit in-image offset bound here (a 1080p float tap is 531 MB
+  // per image at 64 channels and must pass); only the grid's limits apply
+  if (bad_dims("nhwc_to_nchw", n, H, W, prec, 0) || C <= 0) return NQA_E_ARG;
+  if ((long)H * W > (1L << 31) - 64 || n > 65535 || C > 65535 * 64) {  // grid = (HW/64, C/64, n)
+    set_error("nhwc_to_nchw: map too large for the launch grid (H*W=%ld, C=%d, n=%d)", (long)H * W, C, n);
+    return NQA_E_SHAPE;
+  }
   return nhwc_to_nchw(in, n, H * W, C, prec, out, static_cast<hipStream_t>(stream));
 }
 

@@ -1117,8 +1117,10 @@ static int current_device() {
   return hipGetDevice(&dev) == hipSuccess ? dev : 0;
 }
 
-static int g_conv_variant = 1;  // 0: 4-wave tiles everywhere; 1: + 8-wave 256x256 tiles; 2: + 8-wave 128x512 tiles
-static int g_stage1_variant = 0;  // 0: persistent two-phase kernel (conv1_fused_kernel); 1: conv1_tile_kernel
+// thread-local: a tuning choice made by one thread (tools timing variants against each other) never changes what
+// another thread's calls launch
+static thread_local int g_conv_variant = 1;  // 0: 4-wave tiles everywhere; 1: + 8-wave 256x256 tiles; 2: + 8-wave 128x512 tiles
+static thread_local int g_stage1_variant = 0;  // 0: persistent two-phase kernel (conv1_fused_kernel); 1: conv1_tile_kernel
 void set_conv_variant(int v) {
   g_conv_variant = v & 3;
   g_stage1_variant = (v >> 2) & 1;
@@ -1202,7 +1204,17 @@ static int launch_conv(const void *in, int n, int H, int W, int layer, const cha
 #undef NQA_GO
 }
 
-static int g_num_cus = 0;
+// compute units of the current device (cached per device: a process may drive several)
+static int num_cus() {
+  static int cus[64] = {0};
+  const int dev = current_device() & 63;
+  if (!cus[dev]) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    cus[dev] = prop.multiProcessorCount;
+  }
+  return cus[dev];
+}
 
 template <typename P>
 static int launch_conv1_fused(const float *x, const float *y, int B, int n, int H, int W, const char *packed,
@@ -1218,14 +1230,10 @@ static int launch_conv1_fused(const float *x, const float *y, int B, int n, int 
     }
     attr_done = true;
   }
+  const int g_num_cus = num_cus();
   if (!g_num_cus) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
-      set_error("conv1_fused: cannot query the device");
-      return NQA_E_LAUNCH;
-    }
-    g_num_cus = prop.multiProcessorCount;
+    set_error("conv1_fused: cannot query the device");
+    return NQA_E_LAUNCH;
   }
   const int tiles_x = cdiv(W, 32), tiles_y = cdiv(H, 4), total = n * tiles_x * tiles_y;
   const int grid = cdiv(total, 2) < g_num_cus ? cdiv(total, 2) : g_num_cus;  // one persistent block per CU

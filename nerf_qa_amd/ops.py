@@ -30,11 +30,22 @@ def _need_cuda(*ts: torch.Tensor) -> torch.device:
                                 "(move inputs and the module to cuda; there is no CPU fallback)" % t.device)
         if t.device != dev:
             raise _lib.NqaError("tensors on different devices")
-    # the library launches on the current HIP device; make that the tensors' device (a process that
-    # drives several GPUs from one thread would otherwise launch on the wrong one and fault)
-    if dev.index is not None and dev.index != torch.cuda.current_device():
-        torch.cuda.set_device(dev)
     return dev
+
+
+def _on(dev: torch.device):
+    """The library launches on the current HIP device: make that the tensors' device for the duration of the
+    call and restore the caller's afterwards (a process that drives several GPUs from one thread would
+    otherwise launch on the wrong one -- or, if we left it switched, allocate on the wrong one later)."""
+    return torch.cuda.device(dev)
+
+
+def _call(dev: torch.device, fn, *args) -> None:
+    if dev.index is not None and dev.index != torch.cuda.current_device():
+        with _on(dev):
+            check(fn(*args))
+    else:
+        check(fn(*args))
 
 
 def _f32c(t: torch.Tensor) -> torch.Tensor:
@@ -84,7 +95,7 @@ def conv1_1(x: torch.Tensor, packed: torch.Tensor, prec) -> torch.Tensor:
     n, c, h, w = x.shape
     assert c == 3
     out = torch.empty((n, h, w, 64), dtype=PREC_DTYPE[p], device=dev)
-    check(lib().nqa_conv1_1(ptr(x), n, h, w, ptr(packed), p, ptr(out), stream_ptr(dev)))
+    _call(dev, lib().nqa_conv1_1, ptr(x), n, h, w, ptr(packed), p, ptr(out), stream_ptr(dev))
     return out
 
 
@@ -96,7 +107,7 @@ def conv1_fused(x: torch.Tensor, packed: torch.Tensor, prec) -> torch.Tensor:
     n, c, h, w = x.shape
     assert c == 3
     out = torch.empty((n, h, w, 64), dtype=PREC_DTYPE[p], device=dev)
-    check(lib().nqa_conv1_fused(ptr(x), n, h, w, ptr(packed), p, ptr(out), stream_ptr(dev)))
+    _call(dev, lib().nqa_conv1_fused, ptr(x), n, h, w, ptr(packed), p, ptr(out), stream_ptr(dev))
     return out
 
 
@@ -108,7 +119,7 @@ def conv3x3_relu(inp: torch.Tensor, layer: int, packed: torch.Tensor, prec) -> t
     n, h, w, c = inp.shape
     assert c == CONV_CIN[layer]
     out = torch.empty((n, h, w, CONV_COUT[layer]), dtype=inp.dtype, device=dev)
-    check(lib().nqa_conv3x3_relu(ptr(inp), n, h, w, layer, ptr(packed), p, ptr(out), stream_ptr(dev)))
+    _call(dev, lib().nqa_conv3x3_relu, ptr(inp), n, h, w, layer, ptr(packed), p, ptr(out), stream_ptr(dev))
     return out
 
 
@@ -119,7 +130,7 @@ def l2pool(inp: torch.Tensor, prec) -> torch.Tensor:
     assert inp.dtype == PREC_DTYPE[p] and inp.is_contiguous()
     n, h, w, c = inp.shape
     out = torch.empty((n, (h + 1) // 2, (w + 1) // 2, c), dtype=inp.dtype, device=dev)
-    check(lib().nqa_l2pool(ptr(inp), n, h, w, c, p, ptr(out), stream_ptr(dev)))
+    _call(dev, lib().nqa_l2pool, ptr(inp), n, h, w, c, p, ptr(out), stream_ptr(dev))
     return out
 
 
@@ -129,7 +140,7 @@ def nhwc_to_nchw_f32(inp: torch.Tensor, prec) -> torch.Tensor:
     assert inp.dtype == PREC_DTYPE[p] and inp.is_contiguous()
     n, h, w, c = inp.shape
     out = torch.empty((n, c, h, w), dtype=torch.float32, device=dev)
-    check(lib().nqa_nhwc_to_nchw_f32(ptr(inp), n, h, w, c, p, ptr(out), stream_ptr(dev)))
+    _call(dev, lib().nqa_nhwc_to_nchw_f32, ptr(inp), n, h, w, c, p, ptr(out), stream_ptr(dev))
     return out
 
 
@@ -158,7 +169,7 @@ def vgg_pyramid(x: torch.Tensor, packed: torch.Tensor, prec, ws: Workspace | Non
     nbytes = lib().nqa_workspace_bytes(n, h, w, p)
     buf = (ws or Workspace()).get(nbytes, dev)
     tp = (C.c_void_p * 5)(*[ptr(t) for t in taps])
-    check(lib().nqa_vgg_pyramid(ptr(x), n, h, w, ptr(packed), p, ptr(buf), buf.numel(), tp, stream_ptr(dev)))
+    _call(dev, lib().nqa_vgg_pyramid, ptr(x), n, h, w, ptr(packed), p, ptr(buf), buf.numel(), tp, stream_ptr(dev))
     return taps
 
 
@@ -195,8 +206,8 @@ def dists_forward(x: torch.Tensor, y: torch.Tensor, packed: torch.Tensor, prec, 
     s2 = torch.empty((b, TOTAL_CHNS), dtype=torch.float32, device=dev)
     nbytes = lib().nqa_workspace_bytes(2 * b, h, w, p)
     buf = (ws or Workspace()).get(nbytes, dev)
-    check(lib().nqa_dists_forward(ptr(x), ptr(y), b, h, w, ptr(packed), p, ptr(buf), buf.numel(), ptr(s1), ptr(s2),
-                                  stream_ptr(dev)))
+    _call(dev, lib().nqa_dists_forward, ptr(x), ptr(y), b, h, w, ptr(packed), p, ptr(buf), buf.numel(), ptr(s1), ptr(s2),
+                                  stream_ptr(dev))
     return s1, s2
 
 
@@ -221,8 +232,8 @@ def dists_stats_nchw(feats0: Sequence[torch.Tensor], feats1: Sequence[torch.Tens
     scratch = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
     p0 = (C.c_void_p * 6)(*[ptr(f) for f in f0])
     p1 = (C.c_void_p * 6)(*[ptr(f) for f in f1])
-    check(lib().nqa_dists_stats_nchw(p0, p1, b, cs, hs, wsz, ptr(scratch), scratch.numel(), ptr(s1), ptr(s2),
-                                     stream_ptr(dev)))
+    _call(dev, lib().nqa_dists_stats_nchw, p0, p1, b, cs, hs, wsz, ptr(scratch), scratch.numel(), ptr(s1), ptr(s2),
+                                     stream_ptr(dev))
     return s1, s2
 
 
@@ -233,7 +244,7 @@ def dists_score(s1: torch.Tensor, s2: torch.Tensor, alpha: torch.Tensor, beta: t
     a, b_ = _f32c(alpha.detach().reshape(-1)), _f32c(beta.detach().reshape(-1))
     assert s1.shape == s2.shape and s1.shape[1] == TOTAL_CHNS == a.numel() == b_.numel()
     out = torch.empty((s1.shape[0],), dtype=torch.float32, device=dev)
-    check(lib().nqa_dists_score(ptr(s1), ptr(s2), ptr(a), ptr(b_), s1.shape[0], ptr(out), stream_ptr(dev)))
+    _call(dev, lib().nqa_dists_score, ptr(s1), ptr(s2), ptr(a), ptr(b_), s1.shape[0], ptr(out), stream_ptr(dev))
     return out
 
 
@@ -277,11 +288,11 @@ def adists_forward(x: torch.Tensor, y: torch.Tensor, packed: torch.Tensor, prec,
     buf = (ws or Workspace()).get(nbytes, dev)
     if with_map:
         m = torch.empty((b, h, w), dtype=torch.float32, device=dev)
-        check(lib().nqa_adists_forward_map(ptr(x), ptr(y), b, h, w, ptr(packed), p, ptr(buf), buf.numel(), ptr(d),
-                                           ptr(m), stream_ptr(dev)))
+        _call(dev, lib().nqa_adists_forward_map, ptr(x), ptr(y), b, h, w, ptr(packed), p, ptr(buf), buf.numel(), ptr(d),
+                                           ptr(m), stream_ptr(dev))
         return d, m
-    check(lib().nqa_adists_forward(ptr(x), ptr(y), b, h, w, ptr(packed), p, ptr(buf), buf.numel(), ptr(d),
-                                   stream_ptr(dev)))
+    _call(dev, lib().nqa_adists_forward, ptr(x), ptr(y), b, h, w, ptr(packed), p, ptr(buf), buf.numel(), ptr(d),
+                                   stream_ptr(dev))
     return d
 
 
@@ -294,7 +305,7 @@ def u8hwc_to_f32nchw(frames: torch.Tensor, pil_roundtrip: bool = False) -> torch
     frames = frames.contiguous()
     n, h, w, _ = frames.shape
     out = torch.empty((n, 3, h, w), dtype=torch.float32, device=dev)
-    check(lib().nqa_u8hwc_to_f32nchw(ptr(frames), n, h, w, int(pil_roundtrip), ptr(out), stream_ptr(dev)))
+    _call(dev, lib().nqa_u8hwc_to_f32nchw, ptr(frames), n, h, w, int(pil_roundtrip), ptr(out), stream_ptr(dev))
     return out
 
 
@@ -307,7 +318,7 @@ def resize_bilinear_f32(x: torch.Tensor, size) -> torch.Tensor:
     ho, wo = (int(size), int(size)) if isinstance(size, int) else (int(size[0]), int(size[1]))
     n, c, h, w = x.shape
     out = torch.empty((n, c, ho, wo), dtype=torch.float32, device=dev)
-    check(lib().nqa_resize_bilinear_f32(ptr(x), n * c, h, w, ho, wo, ptr(out), stream_ptr(dev)))
+    _call(dev, lib().nqa_resize_bilinear_f32, ptr(x), n * c, h, w, ho, wo, ptr(out), stream_ptr(dev))
     return out
 
 
@@ -320,7 +331,7 @@ def u8_resize_bilinear_f32(frames: torch.Tensor, size) -> torch.Tensor:
     ho, wo = (int(size), int(size)) if isinstance(size, int) else (int(size[0]), int(size[1]))
     n, h, w, _ = frames.shape
     out = torch.empty((n, 3, ho, wo), dtype=torch.float32, device=dev)
-    check(lib().nqa_u8_resize_bilinear_f32(ptr(frames), n, h, w, ho, wo, ptr(out), stream_ptr(dev)))
+    _call(dev, lib().nqa_u8_resize_bilinear_f32, ptr(frames), n, h, w, ho, wo, ptr(out), stream_ptr(dev))
     return out
 
 
@@ -335,8 +346,8 @@ def resize_pil_bilinear_u8(frames: torch.Tensor, size, ws: Workspace | None = No
     out = torch.empty((n, ho, wo, 3), dtype=torch.uint8, device=dev)
     nbytes = lib().nqa_resize_pil_workspace_bytes(n, h, w, ho, wo)
     buf = (ws or Workspace()).get(nbytes, dev)
-    check(lib().nqa_resize_pil_bilinear_u8(ptr(frames), n, h, w, ho, wo, ptr(buf), buf.numel(), ptr(out),
-                                           stream_ptr(dev)))
+    _call(dev, lib().nqa_resize_pil_bilinear_u8, ptr(frames), n, h, w, ho, wo, ptr(buf), buf.numel(), ptr(out),
+                                           stream_ptr(dev))
     return out
 
 
@@ -347,7 +358,7 @@ def split16_encode(a: torch.Tensor) -> torch.Tensor:
     a = _f32c(a)
     c = a.shape[-1]
     out = torch.empty_like(a)
-    check(lib().nqa_split16_encode(ptr(a), a.numel() // c, c, ptr(out), stream_ptr(dev)))
+    _call(dev, lib().nqa_split16_encode, ptr(a), a.numel() // c, c, ptr(out), stream_ptr(dev))
     return out
 
 
@@ -356,5 +367,5 @@ def split16_decode(a: torch.Tensor) -> torch.Tensor:
     assert a.dtype == torch.float32 and a.is_contiguous()
     c = a.shape[-1]
     out = torch.empty_like(a)
-    check(lib().nqa_split16_decode(ptr(a), a.numel() // c, c, ptr(out), stream_ptr(dev)))
+    _call(dev, lib().nqa_split16_decode, ptr(a), a.numel() // c, c, ptr(out), stream_ptr(dev))
     return out

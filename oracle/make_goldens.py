@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Pin the oracle against the reference itself and freeze golden vectors.
 
-AUTHORING-CONTAINER ONLY (needs /root/reference).  Run:  python -m oracle.make_goldens
+AUTHORING-CONTAINER ONLY (needs /root/reference).  Run:  python -m oracle.make_goldens [part ...]
+parts: small (seconds), full (BASELINE.json's full-size configs, ~10 min of CPU), variants, video; default all.
 
 What it does
   1. puts oracle/_standin (a local `torchvision` stand-in; the real package is not
@@ -51,15 +52,123 @@ AMAP_CASES = ("64x64", "97x131", "20x20")  # as_map=True goldens (the map of col
 WEIGHT_SEED = 1234
 
 
-def import_reference():
-    sys.path.insert(0, os.path.join(ROOT, "oracle", "_standin"))
-    sys.path.insert(1, REF)
+def import_reference(gain=1.0):
+    """The reference's own classes, with the stand-in torchvision serving synth.vgg16_weights(WEIGHT_SEED, gain)."""
+    if os.path.join(ROOT, "oracle", "_standin") not in sys.path:
+        sys.path.insert(0, os.path.join(ROOT, "oracle", "_standin"))
+        sys.path.insert(1, REF)
     import torchvision.models as tvm
-    np_convs = synth.vgg16_weights(WEIGHT_SEED)
+    np_convs = synth.vgg16_weights(WEIGHT_SEED, gain)
     tvm.WEIGHT_PROVIDER = lambda: np_convs
     from nerf_qa.ADISTS import ADISTS as RefADISTS
     from nerf_qa.DISTS_pytorch.DISTS_pt import DISTS as RefDISTS
     return RefDISTS, RefADISTS, np_convs
+
+
+def published_alpha_beta():
+    ab = torch.load(os.path.join(REF, "nerf_qa", "DISTS_pytorch", "weights.pt"))
+    return ab["alpha"].float(), ab["beta"].float()
+
+
+# ---- BASELINE.json's full-size configs, from the reference itself ------------------------------------
+# configs[1]: B=32 of 256x256; configs[2]: B=8 of 1080p; configs[4]: A-DISTS at 1080p.  The reference is run one
+# pair at a time (its result for a pair does not depend on the batch it sits in; 1080p pairs need several GB each);
+# the GPU tests place these pairs at chosen slots of a full batch.  Two weight sets: the unit-gain stand-in every
+# other golden uses, and gain 1.6, whose activations grow with depth as ImageNet weights' do (relu5_3: mean ~150,
+# max ~1700 at 1080p), so 16-bit range, the L2-pool squaring and the statistics are stressed (SURVEY App. A);
+# gain 1.3 (relu5_3 mean ~10, max ~120 -- the ImageNet-like magnitude) is added for the cheap 256x256 batch.
+FULL_DISTS = [
+    ("b32_256", 256, 256, tuple(range(200, 232)), None, (1.0, 1.3, 1.6)),
+    ("1080p", 1080, 1920, (300, 301, 302), ("blur", "noise10", "indep"), (1.0, 1.6)),
+]
+FULL_ADISTS = [
+    ("b8_256", 256, 256, tuple(range(240, 248)), None, (1.0, 1.6)),
+    ("1080p", 1080, 1920, (310, 311), ("blur", "noise10"), (1.0, 1.6)),
+]
+
+
+def gain_tag(gain):
+    return "" if gain == 1.0 else "_g%d" % round(gain * 10)
+
+
+def fullsize_goldens(gold):
+    alpha, beta = published_alpha_beta()
+    import time
+    for gain in (1.0, 1.3, 1.6):
+        RefDISTS, RefADISTS, np_convs = import_reference(gain)
+        convs = dists_oracle.convs_from_numpy(np_convs)
+        ref_d = RefDISTS(load_weights=False).eval()
+        ref_d.alpha.data, ref_d.beta.data = alpha.clone(), beta.clone()
+        ref_a = RefADISTS().eval()
+        for name, h, w, seeds, kinds, gains in FULL_DISTS:
+            if gain not in gains:
+                continue
+            scores, s1s, s2s, summ = [], [], [], []
+            for i, seed in enumerate(seeds):
+                kind = kinds[i % len(kinds)] if kinds else synth.KINDS[i % 4]
+                xn, yn = synth.frame_pair(seed, h, w, kind)
+                x, y = torch.from_numpy(xn), torch.from_numpy(yn)
+                t0 = time.time()
+                with torch.no_grad():
+                    r = ref_d(x, y)
+                    f0, f1 = dists_oracle.vgg_pyramid(x, convs), dists_oracle.vgg_pyramid(y, convs)
+                    s1, s2 = dists_oracle.dists_stats(f0, f1)
+                    o = dists_oracle.dists_score(s1, s2, alpha, beta)
+                d = (o - r).abs().max().item()
+                assert d <= 2e-6, f"{name} seed {seed}: oracle differs from the reference by {d}"
+                scores.append(r.numpy()), s1s.append(s1.numpy()), s2s.append(s2.numpy())
+                summ.append([[f.mean().item(), f.abs().max().item()] for f in f0])
+                print(f"DISTS {name}{gain_tag(gain)} seed {seed} {kind}: ref={r.item():.6f} |oracle-ref|={d:.1e} "
+                      f"relu5_3 mean/max={summ[-1][5][0]:.3g}/{summ[-1][5][1]:.3g} ({time.time() - t0:.0f}s)", flush=True)
+                del f0, f1
+            kk = [kinds[i % len(kinds)] if kinds else synth.KINDS[i % 4] for i in range(len(seeds))]
+            np.savez(os.path.join(gold, f"full_dists_{name}{gain_tag(gain)}.npz"), h=h, w=w, seeds=np.array(seeds),
+                     kinds=np.array(kk), weight_seed=WEIGHT_SEED, weight_gain=gain, score=np.concatenate(scores),
+                     s1=np.concatenate(s1s), s2=np.concatenate(s2s), feat_x=np.array(summ))
+        for name, h, w, seeds, kinds, gains in FULL_ADISTS:
+            if gain not in gains:
+                continue
+            scores = []
+            for i, seed in enumerate(seeds):
+                kind = kinds[i % len(kinds)] if kinds else synth.KINDS[i % 4]
+                xn, yn = synth.frame_pair(seed, h, w, kind)
+                x, y = torch.from_numpy(xn), torch.from_numpy(yn)
+                t0 = time.time()
+                with torch.no_grad():
+                    r = ref_a(x, y, as_loss=False)
+                    o = adists_oracle.adists(x, y, convs, as_loss=False)
+                d = (o - r).abs().max().item()
+                assert d <= 2e-6, f"{name} seed {seed}: A-DISTS oracle differs from the reference by {d}"
+                scores.append(r.numpy())
+                print(f"ADISTS {name}{gain_tag(gain)} seed {seed} {kind}: ref={r.item():.6f} |oracle-ref|={d:.1e} "
+                      f"({time.time() - t0:.0f}s)", flush=True)
+            kk = [kinds[i % len(kinds)] if kinds else synth.KINDS[i % 4] for i in range(len(seeds))]
+            np.savez(os.path.join(gold, f"full_adists_{name}{gain_tag(gain)}.npz"), h=h, w=w, seeds=np.array(seeds),
+                     kinds=np.array(kk), weight_seed=WEIGHT_SEED, weight_gain=gain, score=np.concatenate(scores))
+
+
+# ---- the video harness's column arithmetic (prep.py:191-198, test2_prep.py:123-125,158-168) --------------
+def video_goldens(gold):
+    """The reference's scripts cannot be imported (they run on import against private datasets), so the few numpy
+    expressions they apply to the per-frame score arrays are evaluated here, verbatim, on synthetic float32 score
+    vectors; nerf_qa_amd.video must reproduce the results to the bit / to the character."""
+    def to_str(array):                                   # test2_prep.py:123-125
+        array = ['{:.6e}'.format(num) for num in array]
+        return str(array)
+    rng = np.random.default_rng(7)
+    out = {}
+    for k, n in enumerate((1, 5, 200, 1001)):
+        batches = [rng.uniform(0.0, 0.4, m).astype(np.float32) for m in ([8] * (n // 8) + ([n % 8] if n % 8 else []))]
+        frame = np.concatenate(batches)                  # test2_prep.py:156-157
+        out[f"v{k}_scores"] = frame
+        out[f"v{k}_cols"] = np.array([np.mean(frame), np.std(frame), np.min(frame), np.max(frame)])  # :158-165
+        assert out[f"v{k}_cols"].dtype == np.float32
+        bias = np.mean(frame) - frame                    # :167-168
+        out[f"v{k}_bias"] = bias
+        out[f"v{k}_bias_str"] = np.array(to_str(bias))   # :179-180
+        out[f"v{k}_batches"] = np.array(len(batches))    # :181 len(frames_data)
+    np.savez(os.path.join(gold, "video_columns.npz"), **out)
+    print("video column goldens:", {k: out[f"v{k}_cols"] for k in range(4)})
 
 
 VARIANT_CONFIGS = [  # (weight_lower_bound, alpha_beta_ratio, dists_weight_norm, detach_beta)
@@ -126,8 +235,55 @@ def variant_goldens(gold):
         out[f"head_{kind}_scores"], out[f"head_{kind}_dists"], out[f"head_{kind}_entropy"] = \
             scores.numpy(), ds.numpy(), np.array(ent.item())
         print(f"head {kind}: params {out[f'head_{kind}_params']} scores {scores.numpy()}")
+    # nerf_qa/model.py:22-56: the `wandb.config.mode` variant of NeRFQAModel
+    from nerf_qa.model import NeRFQAModel as RefModeModel
+    cfg.weight_lower_bound, cfg.alpha_beta_ratio, cfg.dists_weight_norm, cfg.detach_beta = 1e-4, 1.0, "relu", "False"
+    for mode in ("linear", "sqrt", "softmax", "softmax+sqrt"):
+        cfg.mode = mode
+        M = RefModeModel(df).eval()
+        with torch.no_grad():
+            scores, ds = M(x, y)
+        key = mode.replace("+", "_")
+        out[f"mode_{key}_params"] = np.array([M.dists_weight.item(), M.dists_bias.item()])
+        out[f"mode_{key}_scores"], out[f"mode_{key}_dists"] = scores.numpy(), ds.numpy()
+        print(f"model.py mode {mode}: params {out[f'mode_{key}_params']} scores {scores.numpy()}")
     torch.load = real_load
+    # canonical DISTS.project_weights (DISTS_pt.py:82-89) on the published and on perturbed alpha/beta
+    from nerf_qa.DISTS_pytorch.DISTS_pt import DISTS as RefDISTS
+    alpha, beta = published_alpha_beta()
+    g = torch.Generator().manual_seed(3)
+    for tag, (a0, b0) in {"pub": (alpha, beta), "pert": (alpha + 0.01 * torch.randn(alpha.shape, generator=g),
+                                                         beta - 0.002 * torch.rand(beta.shape, generator=g))}.items():
+        m = RefDISTS(load_weights=False)
+        m.alpha.data, m.beta.data = a0.clone(), b0.clone()
+        m.project_weights()
+        out[f"proj_{tag}_in_alpha"], out[f"proj_{tag}_in_beta"] = a0.numpy().reshape(-1), b0.numpy().reshape(-1)
+        out[f"proj_{tag}_alpha"], out[f"proj_{tag}_beta"] = m.alpha.data.numpy().reshape(-1), m.beta.data.numpy().reshape(-1)
     np.savez(os.path.join(gold, "variants_64x64.npz"), **out)
+    prepare_image_goldens(gold)
+
+
+def prepare_image_goldens(gold):
+    """prepare_image of DISTS_pt (:210-217) and DISTS_pt_original (:140-144) run on seeded PIL images (the
+    stand-in transforms are Pillow-backed): output shapes and pixels for every resize policy."""
+    from PIL import Image
+    from nerf_qa.DISTS_pytorch.DISTS_pt import prepare_image as ref_prep
+    from nerf_qa.DISTS_pytorch.DISTS_pt_original import prepare_image as ref_prep_orig
+    out = {}
+    for k, (h, w) in enumerate(((300, 420), (540, 300), (200, 640), (256, 256), (1080, 1920))):
+        arr = (synth.uniform(900 + k, h * w * 3).reshape(h, w, 3) * 256).astype(np.uint8)
+        img = Image.fromarray(arr, "RGB")
+        calls = {"sq": lambda: ref_prep(img), "keep": lambda: ref_prep(img, resize=True, keep_aspect_ratio=True),
+                 "none": lambda: ref_prep(img, resize=False), "orig": lambda: ref_prep_orig(img),
+                 "orig_none": lambda: ref_prep_orig(img, resize=False)}
+        for tag, fn in calls.items():
+            t = fn()
+            out[f"p{k}_{tag}_shape"] = np.array(t.shape)
+            out[f"p{k}_{tag}_sum"] = np.array(t.double().sum().item())
+            out[f"p{k}_{tag}_u8"] = (t[0, :, ::37, ::41] * 255).round().to(torch.uint8).numpy()  # sparse sample
+        out[f"p{k}_hw"] = np.array([h, w])
+    np.savez(os.path.join(gold, "prepare_image.npz"), **out)
+    print("prepare_image goldens:", {k: out[k].tolist() for k in out if k.endswith("orig_shape")})
 
 
 def feat_summary(feats):
@@ -137,6 +293,22 @@ def feat_summary(feats):
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(os.cpu_count())
+    parts = set(sys.argv[1:]) or {"small", "full", "variants", "video"}
+    gold = os.path.join(ROOT, "tests", "golden")
+    os.makedirs(gold, exist_ok=True)
+    if "video" in parts:
+        video_goldens(gold)
+    if "full" in parts:
+        fullsize_goldens(gold)
+    if "variants" in parts:
+        import_reference()
+        variant_goldens(gold)
+    if "small" in parts:
+        small_goldens(gold)
+    print("goldens written to", gold)
+
+
+def small_goldens(gold):
     RefDISTS, RefADISTS, np_convs = import_reference()
     convs = dists_oracle.convs_from_numpy(np_convs)
     ab = torch.load(os.path.join(REF, "nerf_qa", "DISTS_pytorch", "weights.pt"))
@@ -149,9 +321,6 @@ def main():
     ref_d.alpha.data = alpha.clone()
     ref_d.beta.data = beta.clone()
     ref_a = RefADISTS().eval()
-    gold = os.path.join(ROOT, "tests", "golden")
-    os.makedirs(gold, exist_ok=True)
-
     for name, h, w, seeds, kinds in DISTS_CASES:
         xn, yn = synth.frame_batch(seeds, h, w, kinds)
         x, y = torch.from_numpy(xn), torch.from_numpy(yn)
@@ -204,12 +373,9 @@ def main():
                      h=h, w=w, seeds=np.array(seeds), kinds=np.array(kinds), weight_seed=WEIGHT_SEED,
                      shape=np.array(r_map.shape), map=r_map[:, 0].numpy())
 
-    variant_goldens(gold)
-
     # weight fingerprint so a drift of the generator is caught on the GPU box too
     fp = np.array([[float(np.abs(w_).sum()), float(b_.sum())] for w_, b_ in np_convs])
     np.savez(os.path.join(gold, "vgg_fingerprint.npz"), weight_seed=WEIGHT_SEED, fp=fp)
-    print("goldens written to", gold)
 
 
 if __name__ == "__main__":

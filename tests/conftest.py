@@ -8,6 +8,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# the tests ask for the deterministic stand-in VGG weights explicitly (nerf_qa_amd/vgg_weights.py refuses to
+# fall back to them silently); a test that needs another set passes vgg16_path=
+os.environ.setdefault("NQA_VGG16_WEIGHTS", "synth:1234")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -103,17 +103,30 @@ def test_policies_end_to_end(dev):
     assert torch.equal(a, b)
 
 
-def test_score_video_from_uint8_frames(dev):
-    """The harness accepts decoded uint8 frames and prepares them per batch on the device."""
-    import warnings
-    from nerf_qa_amd import prep, video
+def test_score_video_against_the_oracle(dev, oracle_convs, alpha_beta):
+    """The harness (decoded uint8 frames -> per-batch preparation on the device -> DISTS + A-DISTS -> columns)
+    against the CPU oracles end to end: frames prepared by prep_oracle (prep.py:89-95), scored by the DISTS /
+    A-DISTS oracles, folded into columns by the reference's float32 numpy expressions (test2_prep.py:158-168)."""
+    from nerf_qa_amd import video
+    from nerf_qa_amd.ADISTS import ADISTS
     from nerf_qa_amd.DISTS_pytorch import DISTS
-    ref = torch.from_numpy(_frames(8, 5, 300, 400)).to(dev)
-    ren = torch.from_numpy(_frames(9, 5, 300, 400)).to(dev)
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        m = DISTS().to(dev).eval()
-    cols = video.score_video(ref, ren, dists_model=m, batch_size=2, policy="interp256")
-    want = m(prep.prepare_frames(ref, "interp256"), prep.prepare_frames(ren, "interp256")).detach().cpu().numpy()
-    assert abs(cols["DISTS"] - float(np.mean(want.astype(np.float64)))) < 1e-6
-    assert abs(cols["DISTS_max"] - float(want.max())) < 1e-6
+    from oracle import adists_oracle, dists_oracle, prep_oracle
+    ref_u8, ren_u8 = _frames(8, 5, 300, 400), _frames(9, 5, 300, 400)
+    a, b = (prep_oracle.interp(prep_oracle.to_tensor_roundtrip(f), (256, 256)) for f in (ref_u8, ren_u8))
+    want_d = dists_oracle.dists(a, b, oracle_convs, *alpha_beta).numpy()
+    want_a = adists_oracle.adists(a, b, oracle_convs).numpy()
+    m, am = DISTS(precision="f32s").to(dev).eval(), ADISTS().to(dev).eval()
+    cols = video.score_video(torch.from_numpy(ref_u8).to(dev), torch.from_numpy(ren_u8).to(dev), dists_model=m,
+                             adists_model=am, batch_size=2, policy="interp256", return_frame_scores=True)
+    got = cols.pop("_frame_scores")
+    assert got["DISTS"].dtype == np.float32 and np.abs(got["DISTS"] - want_d).max() <= 5e-6
+    assert np.abs(got["A-DISTS"] - want_a).max() <= 2e-5
+    for name, want in (("DISTS", want_d), ("A-DISTS", want_a)):
+        for suffix, fn in (("", np.mean), ("_std", np.std), ("_min", np.min), ("_max", np.max)):
+            v = cols[name + suffix]
+            assert isinstance(v, np.float32) and abs(v - fn(want)) <= 2e-5, (name, suffix, v, fn(want))
+    assert cols["frame_count"] == 3  # batches of 2 over 5 frames, as len(DataLoader) counts (test2_prep.py:181)
+    bias = np.array([float(t) for t in eval(cols["frame_bias_dists"])])
+    assert bias.shape == (5,) and np.abs(bias - (np.mean(want_d) - want_d)).max() <= 1e-5
+    assert list(cols) == ["A-DISTS", "A-DISTS_std", "A-DISTS_min", "A-DISTS_max", "DISTS", "DISTS_std", "DISTS_min",
+                          "DISTS_max", "frame_count", "frame_bias_adists", "frame_bias_dists"]

@@ -98,3 +98,28 @@ def test_adists_window_switch():
     assert adists_oracle.windowed(21, 21) and not adists_oracle.windowed(20, 300)
     g = adists_oracle.gaussian_1d()
     assert g.numel() == 21 and abs(g.sum().item() - 1) < 1e-6 and g.argmax().item() == 10
+
+
+FULL_256 = sorted(glob.glob(os.path.join(GOLDEN, "full_*_256*.npz")))
+
+
+@pytest.mark.parametrize("path", FULL_256, ids=[os.path.basename(p)[:-4] for p in FULL_256])
+def test_oracle_matches_full_size_goldens_256(path):
+    """The full-size goldens (make_goldens `full`) on every weight set, first pairs of each 256x256 file: the
+    oracle with synth.vgg16_weights(seed, gain) reproduces the reference's scores (the 1080p files need a minute
+    of CPU per pair and are checked by make_goldens itself, which asserts oracle == reference while writing them)."""
+    from nerf_qa_amd import synth
+    from oracle import adists_oracle, dists_oracle
+    g = np.load(path)
+    convs = dists_oracle.convs_from_numpy(synth.vgg16_weights(int(g["weight_seed"]), float(g["weight_gain"])))
+    n = 4 if "dists_b32" in path else 2
+    xs, ys = zip(*[synth.frame_pair(int(s), int(g["h"]), int(g["w"]), str(k)) for s, k in
+                   zip(g["seeds"][:n], g["kinds"][:n])])
+    x, y = torch.from_numpy(np.concatenate(xs)), torch.from_numpy(np.concatenate(ys))
+    if "full_adists" in path:
+        got = adists_oracle.adists(x, y, convs, as_loss=False).numpy()
+    else:
+        d = np.load(os.path.join(os.path.dirname(GOLDEN), "..", "nerf_qa_amd", "data", "dists_alpha_beta.npz"))
+        a, b = (torch.from_numpy(d[k]).view(1, -1, 1, 1) for k in ("alpha", "beta"))
+        got = dists_oracle.dists(x, y, convs, a, b).numpy()
+    assert np.abs(got - g["score"][:n]).max() <= 2e-6

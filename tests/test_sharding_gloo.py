@@ -1,4 +1,4 @@
-"""Frame sharding + the single score all-gather, on CPU with the gloo backend (world_size 2).
+"""Frame sharding + the single score all-gather, on CPU with the gloo backend (world_size 2 and 4).
 
 The GPU kernels are not involved: a stub scorer stands in for the model so that the
 partitioning, padding and gather logic of nerf_qa_amd.sharding (what bench.py --gpus N and
@@ -38,9 +38,10 @@ def _worker(rank, world, port, n_frames, batch, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_frames,batch", [(10, 4), (7, 3), (1, 8), (33, 32)])
-def test_sharded_scores_gathered_on_every_rank(n_frames, batch):
-    world = 2
+@pytest.mark.parametrize("world,n_frames,batch", [(2, 10, 4), (2, 7, 3), (2, 1, 8), (2, 33, 32),
+                                                  (4, 10001, 8), (4, 3, 8)],
+                         ids=["w2_10", "w2_7", "w2_1", "w2_33", "w4_10001_uneven", "w4_3_empty_ranks"])
+def test_sharded_scores_gathered_on_every_rank(world, n_frames, batch):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -77,13 +78,3 @@ def test_gather_without_process_group():
     from nerf_qa_amd.sharding import gather_scores
     t = torch.arange(5, dtype=torch.float32)
     assert torch.equal(gather_scores(t, 5), t)
-
-
-def test_video_columns():
-    from nerf_qa_amd.video import format_frame_scores, video_columns
-    s = np.array([0.1, 0.2, 0.4], dtype=np.float32)
-    c = video_columns("DISTS", s)
-    assert abs(c["DISTS"] - float(np.mean(s.astype(np.float64)))) < 1e-12
-    assert abs(c["DISTS_std"] - float(np.std(s.astype(np.float64)))) < 1e-12
-    assert c["DISTS_min"] == pytest.approx(0.1) and c["DISTS_max"] == pytest.approx(0.4)
-    assert format_frame_scores(s[:2]) == "[1.000000e-01, 2.000000e-01]"

@@ -78,3 +78,27 @@ def test_variants_and_head_match_reference(monkeypatch):
             assert np.abs(scores.cpu().numpy() - G[f"head_{kind}_scores"]).max() <= 2e-4  # the head multiplies by ~8
             assert abs(ent.item() - float(G[f"head_{kind}_entropy"])) <= 1e-4 * abs(float(G[f"head_{kind}_entropy"]))
     _cfg(0.0, 1.0, "off", "False")
+
+
+@pytest.mark.gpu
+def test_mode_model_matches_reference(monkeypatch):
+    """nerf_qa/model.py:22-56 (the wandb.config.mode variant four entry scripts import): scores of every mode."""
+    from nerf_qa_amd import config as cfgmod, synth
+    from nerf_qa_amd.model import NeRFQAModel
+    monkeypatch.setenv("NQA_PRECISION", "f32")
+    dev = torch.device("cuda:0")
+    xn, yn = synth.frame_batch([int(s) for s in G["seeds"]], int(G["h"]), int(G["w"]))
+    x, y = torch.from_numpy(xn).to(dev), torch.from_numpy(yn).to(dev)
+    c = _cfg(1e-4, 1.0, "relu", "False")
+    try:
+        for mode in ("linear", "sqrt", "softmax", "softmax+sqrt"):
+            c.mode = mode
+            M = NeRFQAModel(_df()).to(dev).eval()
+            with torch.no_grad():
+                scores, ds = M(x, y)
+            key = "mode_" + mode.replace("+", "_")
+            assert np.abs(ds.cpu().numpy() - G[key + "_dists"]).max() <= 5e-6
+            assert np.abs(scores.cpu().numpy() - G[key + "_scores"]).max() <= 2e-4  # the head multiplies by ~8
+    finally:
+        c.mode = "linear"
+        _cfg(0.0, 1.0, "off", "False")

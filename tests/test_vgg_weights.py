@@ -1,6 +1,4 @@
 """The VGG-16 checkpoint path: a local torchvision-format state dict replaces the stand-in weights."""
-import warnings
-
 import numpy as np
 import pytest
 import torch
@@ -42,13 +40,21 @@ def test_bad_checkpoint_is_refused(tmp_path):
         load_vgg16_convs(str(p))
 
 
-def test_stand_in_warns(monkeypatch):
+def test_stand_in_must_be_requested(monkeypatch):
+    """No silent stand-in: without a named source construction raises; 'synth[:seed[:gain]]' asks for it."""
+    from nerf_qa_amd import NqaError, synth
     from nerf_qa_amd.vgg_weights import load_vgg16_convs
     monkeypatch.delenv("NQA_VGG16_WEIGHTS", raising=False)
-    with warnings.catch_warnings(record=True) as rec:
-        warnings.simplefilter("always")
-        _, tag = load_vgg16_convs()
-    assert tag == "synth:1234" and any("stand-in" in str(r.message) for r in rec)
+    with pytest.raises(NqaError):
+        load_vgg16_convs()
+    convs, tag = load_vgg16_convs("synth")
+    assert tag == "synth:1234" and np.array_equal(convs[3][0].numpy(), synth.vgg16_weights(1234)[3][0])
+    convs, tag = load_vgg16_convs("synth:7:1.6")
+    assert tag == "synth:7:1.6" and np.array_equal(convs[12][0].numpy(), synth.vgg16_weights(7, 1.6)[12][0])
+    monkeypatch.setenv("NQA_VGG16_WEIGHTS", "synth:5")
+    assert load_vgg16_convs()[1] == "synth:5"
+    with pytest.raises(ValueError):
+        load_vgg16_convs("synth:1:2:3")
 
 
 @pytest.mark.gpu

@@ -1,4 +1,5 @@
 """A-DISTS f16 / f32 vs the CPU oracle on structured frames (development aid)."""
+import os; os.environ.setdefault("NQA_VGG16_WEIGHTS", "synth:1234")  # dev tool: stand-in weights, asked for explicitly
 import sys
 import warnings
 import torch

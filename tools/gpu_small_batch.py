@@ -1,4 +1,5 @@
 """Throughput vs batch size through the module surface (is the small-batch path launch-bound?)."""
+import os; os.environ.setdefault("NQA_VGG16_WEIGHTS", "synth:1234")  # dev tool: stand-in weights, asked for explicitly
 import sys, time, warnings
 import torch
 sys.path.insert(0, __file__.rsplit("/", 2)[0])

@@ -1,6 +1,7 @@
 """One-off randomized stress: many random frame sizes through both metrics against the CPU oracle, with a fenced
 workspace (prints the worst deviations; exits non-zero on a parity or fence failure)."""
-import sys, warnings
+import os; os.environ.setdefault("NQA_VGG16_WEIGHTS", "synth:1234")  # dev tool: stand-in weights, asked for explicitly
+import json, sys, warnings
 import numpy as np
 import torch
 sys.path.insert(0, __file__.rsplit("/", 2)[0])
@@ -22,10 +23,12 @@ convs = dists_oracle.convs_from_numpy(synth.vgg16_weights(1234))
 rng = np.random.default_rng(99)
 worst = {"f16": 0.0, "f32s": 0.0, "a32s": 0.0}
 flips = 0
+cases = []  # inputs of every A-DISTS deviation above 1e-4, for oracle/knife_edge_study.py
 for i in range(N):
     h, w, b = int(rng.integers(LO, HI + 1)), int(rng.integers(LO, HI + 1)), int(rng.integers(1, BMAX + 1))
     kinds = [synth.KINDS[int(k)] for k in rng.integers(0, 4, b)]
-    xn, yn = synth.frame_batch([int(s) for s in rng.integers(0, 10 ** 6, b)], h, w, kinds)
+    seeds = [int(s) for s in rng.integers(0, 10 ** 6, b)]
+    xn, yn = synth.frame_batch(seeds, h, w, kinds)
     x, y = torch.from_numpy(xn), torch.from_numpy(yn)
     with torch.no_grad():
         ref = dists_oracle.dists(x, y, convs, m16.alpha.detach().cpu(), m16.beta.detach().cpu())
@@ -40,6 +43,12 @@ for i in range(N):
     if ea > 1e-4:
         flips += 1
         print(f"  A-DISTS knife edge? {h}x{w} b={b} kinds={kinds}: |d|={ea:.2e}", flush=True)
+        for j in range(b):
+            if ok[j] and abs(ga[j].item() - aref[j].item()) > 1e-4:
+                cases.append({"iter": i, "h": h, "w": w, "seed": seeds[j], "kind": kinds[j], "slot": j, "batch": b,
+                              "hip_f32s": ga[j].item(), "oracle_f32": aref[j].item()})
+        os.makedirs("gpurun_out", exist_ok=True)
+        json.dump(cases, open("gpurun_out/knife_cases.json", "w"), indent=1)
     assert e16 <= 1e-4 and e32 <= 5e-6, (h, w, b, e16, e32)
     worst = {"f16": max(worst["f16"], e16), "f32s": max(worst["f32s"], e32), "a32s": max(worst["a32s"], ea)}
     if i % 25 == 24:

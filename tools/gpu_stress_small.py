@@ -1,4 +1,5 @@
 """Tail of the f16 DISTS error on small frames (where the statistics run over few pixels)."""
+import os; os.environ.setdefault("NQA_VGG16_WEIGHTS", "synth:1234")  # dev tool: stand-in weights, asked for explicitly
 import sys, warnings
 import numpy as np
 import torch
