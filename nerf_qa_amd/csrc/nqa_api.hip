@@ -61,7 +61,8 @@ TimedLaunch::~TimedLaunch() {
 static size_t layer_bytes(int layer, int prec) {
   const ConvSpec &c = kConvs[layer];
   if (layer == 0) return align_up(27 * 64 * 4 + 64 * 4, 256) + 6144;
-  return align_up((size_t)c.cin * c.cout * 9 * prec_elem_bytes(prec), 256) + align_up((size_t)c.cout * 4, 256);
+  // weights, then float bias[cout] followed by ONE float: 1 / (the layer's power-of-two weight scale)
+  return align_up((size_t)c.cin * c.cout * 9 * prec_elem_bytes(prec), 256) + align_up((size_t)c.cout * 4 + 4, 256);
 }
 size_t layer_offset(int layer, int prec) {
   size_t o = kZeroPage;
@@ -323,8 +324,27 @@ int nqa_pack_vgg_weights(const float *const w_host[NQA_NUM_CONVS], const float *
     const ConvSpec &cs = kConvs[l];
     const int bn = 64, ncc = cs.cin / kc;
     char *dst = blob + layer_offset(l, prec);
+    {  // 1 / weight scale behind the bias (1 in every mode but f32s)
+      float one = 1.f;
+      memcpy(blob + layer_bias_offset(l, prec) + (size_t)cs.cout * 4, &one, 4);
+    }
     if (prec == NQA_PREC_F32S) {
-      // rows of 16 input channels as [hi 0-7 | hi 8-15 | lo 0-7 | lo 8-15] halves, lo = f16(w - hi)
+      // rows of 16 input channels as [hi 0-7 | hi 8-15 | lo 0-7 | lo 8-15] halves, lo = f16(w*s - hi).
+      // s is a power of two per layer that puts the layer's largest |w| in [512, 1024): a VGG weight is
+      // ~1e-2, whose residual after the f16 `hi` (~5e-6) is a SUBNORMAL half with an absolute quantum of 6e-8
+      // -- 25 times coarser than float32 relative to the weight, which left 2e-6 of noise on every
+      // pre-activation and flipped nearly-dead channels of A-DISTS (oracle/knife_edge_study.py).  Scaled,
+      // hi and lo are both normal halves (22-23 significant bits together); the scale is exact and the
+      // conv epilogue multiplies the accumulator by 1/s (also exact) before the bias.
+      float wmax = 0.f;
+      for (size_t i = 0; i < (size_t)cs.cout * cs.cin * 9; ++i) wmax = fmaxf(wmax, fabsf(w_host[l][i]));
+      int k = 0;
+      if (wmax > 0.f && isfinite(wmax)) {
+        k = (int)floor(log2(1024.0 / (double)wmax));
+        k = k < -8 ? -8 : (k > 24 ? 24 : k);
+      }
+      const float wscale = ldexpf(1.f, k), winv = ldexpf(1.f, -k);
+      memcpy(blob + layer_bias_offset(l, prec) + (size_t)cs.cout * 4, &winv, 4);
       for (int ct = 0; ct < cs.cout / bn; ++ct)
         for (int cc = 0; cc < ncc; ++cc)
           for (int t = 0; t < 9; ++t)
@@ -334,7 +354,7 @@ int nqa_pack_vgg_weights(const float *const w_host[NQA_NUM_CONVS], const float *
                 uint16_t *row = reinterpret_cast<uint16_t *>(dst) + (((((size_t)ct * ncc + cc) * 9 + t) * bn + n) * 4 + pos) * 8;
                 for (int j = 0; j < 8; ++j) {
                   const int cin = cc * 16 + (c & 1) * 8 + j, cout = ct * bn + n;
-                  const float v = w_host[l][((size_t)cout * cs.cin + cin) * 9 + t];
+                  const float v = w_host[l][((size_t)cout * cs.cin + cin) * 9 + t] * wscale;
                   const uint16_t hi = f32_to_f16(v);
                   row[j] = c < 2 ? hi : f32_to_f16(v - f16_to_f32(hi));
                 }

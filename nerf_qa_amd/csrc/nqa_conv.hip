@@ -484,10 +484,18 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void conv3x3_igemm_kernel(
   char *const obase = reinterpret_cast<char *>(out) + (size_t)ct * RB;
   const size_t rec = (size_t)Cout * sizeof(T);
   // one lane's piece: 4 consecutive channels (first = cl, block-local) of the pixel staged in `row`
+  // f32s: the weights were packed times a power of two (nqa_pack_vgg_weights); 1/scale sits behind the bias
+  const float winv = P::SPLIT ? bias[Cout] : 1.f;
   auto stage_piece = [&](int row, int cl, float a0, float a1, float a2, float a3) {
     char *const rbase = smem + row * RB;
     const int sw = row & SWZ;
     const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bias + ct * G::BN + cl);
+    if constexpr (P::SPLIT) {  // exact: winv is a power of two
+      a0 *= winv;
+      a1 *= winv;
+      a2 *= winv;
+      a3 *= winv;
+    }
     const float v[4] = {fmaxf(a0 + b4[0], 0.f), fmaxf(a1 + b4[1], 0.f), fmaxf(a2 + b4[2], 0.f),
                         fmaxf(a3 + b4[3], 0.f)};
     if constexpr (sizeof(T) == 4) {

@@ -79,7 +79,7 @@ def test_pack_roundtrip(prec, np_convs, lib):
                     assert np.array_equal(wm[ky, :, hh, j], want)
     for l in (1, 2, 7, 12):
         cin, cout = ops.CONV_CIN[l], ops.CONV_COUT[l]
-        o = off + sum(al(ops.CONV_CIN[i] * ops.CONV_COUT[i] * 9 * esz) + al(ops.CONV_COUT[i] * 4) for i in range(1, l))
+        o = off + sum(al(ops.CONV_CIN[i] * ops.CONV_COUT[i] * 9 * esz) + al(ops.CONV_COUT[i] * 4 + 4) for i in range(1, l))
         w = np_convs[l][0]
         if prec == "f32":
             got = _unpack_layer(blob, o, cin, cout, np.float32, 4)
@@ -91,12 +91,14 @@ def test_pack_roundtrip(prec, np_convs, lib):
             got = _unpack_layer(blob, o, cin, cout, np.uint16, 8, m16=l >= 2)
             ref = torch.from_numpy(w).to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)
             assert np.array_equal(got, ref)
-        bias = blob[o + al(cin * cout * 9 * esz):][:cout * 4].view(np.float32)
-        assert np.array_equal(bias, np_convs[l][1])
+        bias = blob[o + al(cin * cout * 9 * esz):][:cout * 4 + 4].view(np.float32)
+        assert np.array_equal(bias[:cout], np_convs[l][1]) and bias[cout] == 1.0  # no weight scale in these modes
 
 
 def test_pack_split_f16(np_convs, lib):
-    """f32s blob: every weight as an f16 (hi, lo) pair, hi + lo == w to ~2^-21, rows [hi0-7|hi8-15|lo0-7|lo8-15]."""
+    """f32s blob: every weight, times the layer's power-of-two scale s (largest |w|*s in [512, 1024): hi and lo both
+    NORMAL halves), as an f16 (hi, lo) pair, rows [hi0-7|hi8-15|lo0-7|lo8-15]; 1/s follows the bias.
+    (hi + lo)/s == w to 2^-22 relative -- float32-class, where unscaled weights (~1e-2, lo subnormal) reach 2^-19."""
     from nerf_qa_amd import ops
     blob = ops.pack_vgg_weights(np_convs, "f32s").numpy()
     assert blob.nbytes == ops.pack_vgg_weights(np_convs, "f32").numpy().nbytes
@@ -104,7 +106,7 @@ def test_pack_split_f16(np_convs, lib):
     off = 256 + al(27 * 64 * 4 + 64 * 4) + 6144
     for l in (1, 4, 12):
         cin, cout = ops.CONV_CIN[l], ops.CONV_COUT[l]
-        o = off + sum(al(ops.CONV_CIN[i] * ops.CONV_COUT[i] * 9 * 4) + al(ops.CONV_COUT[i] * 4) for i in range(1, l))
+        o = off + sum(al(ops.CONV_CIN[i] * ops.CONV_COUT[i] * 9 * 4) + al(ops.CONV_COUT[i] * 4 + 4) for i in range(1, l))
         ncc = cin // 16
         t = blob[o:o + cin * cout * 36].view(np.float16).reshape(cout // 64, ncc, 9, 64, 4, 8)
         w = np_convs[l][0].reshape(cout, cin, 9)
@@ -117,12 +119,18 @@ def test_pack_split_f16(np_convs, lib):
                 for cc in range(ncc):
                     ch = cc * 16 + (c & 1) * 8
                     dst[n::64, ch:ch + 8, :] = t[:, cc, :, n, pos, :].transpose(0, 2, 1)
-        assert np.array_equal(hi, w.astype(np.float16))
-        assert np.array_equal(lo, (w - hi.astype(np.float32)).astype(np.float16))
-        rec = hi.astype(np.float64) + lo.astype(np.float64)
-        assert np.abs(rec - w).max() <= 2.0 ** -21 * np.abs(w).max()
-        bias = blob[o + al(cin * cout * 36):][:cout * 4].view(np.float32)
-        assert np.array_equal(bias, np_convs[l][1])
+        bias = blob[o + al(cin * cout * 36):][:cout * 4 + 4].view(np.float32)
+        assert np.array_equal(bias[:cout], np_convs[l][1])
+        inv = float(bias[cout])
+        scale = 1.0 / inv
+        assert scale == 2.0 ** round(np.log2(scale)) and 512 <= np.abs(w).max() * scale < 1024
+        ws = w * np.float32(scale)
+        assert np.array_equal(hi, ws.astype(np.float16))
+        assert np.array_equal(lo, (ws - hi.astype(np.float32)).astype(np.float16))
+        rec = (hi.astype(np.float64) + lo.astype(np.float64)) * inv
+        big = np.abs(w) > 2.0 ** -10 * np.abs(w).max()  # (weights a thousand times below the largest: absolute bound)
+        assert (np.abs(rec - w)[big] <= 2.0 ** -21 * np.abs(w)[big]).all()
+        assert np.abs(rec - w).max() <= 2.0 ** -22 * np.abs(w).max()
 
 
 @pytest.mark.parametrize("h,w", [(1, 1), (2, 3), (1, 12), (3, 2), (7, 7), (64, 64)])

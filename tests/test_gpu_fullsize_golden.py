@@ -66,7 +66,9 @@ def test_dists_b32_256_vs_reference(gain, dev):
     g = _gold("dists", "b32_256", gain)
     x, y = _pairs(g, dev)
     assert x.shape[0] == 32
-    for prec, tol, stol in (("f16", 1e-4, None), ("f32s", 5e-6, 2e-4), ("f32", 5e-6, 2e-4)):
+    # per-channel S1 / S2 are quotients with c = 1e-6: on nearly dead channels (variance ~1e-6) a 1e-9 difference in
+    # a moment moves S2 by 1e-3, so they get a loose bound; the score (their alpha/beta-weighted sum) is the bar
+    for prec, tol, stol in (("f16", 1e-4, None), ("f32s", 5e-6, 2e-2), ("f32", 5e-6, 2e-2)):
         m = DISTS(precision=prec, vgg16_path=_spec(gain)).to(dev).eval()
         with torch.no_grad():
             got = m(x, y).cpu().numpy()
