@@ -193,7 +193,8 @@ int nqa_resize_pil_bilinear_u8(const uint8_t *in, int n, int Hin, int Win, int H
  * layer, 1 (default) = + 8-wave 256 ch x 256 px tiles on layers with >= 256 output channels, 2 =
  * + 8-wave 128 ch x 512 px tiles wherever the map is large enough (measured equal to 1).
  * Adding 4 selects the second form of the fused stage-1 kernel (an implicit-GEMM tile that computes
- * its conv1_1 halo itself instead of the persistent two-phase kernel; measured within +-6 %).  Results are identical in
+ * its conv1_1 halo itself instead of the persistent two-phase kernel; measured within +-6 %).  Adding 8 selects the
+ * first form of the A-DISTS window pass (every wave loads its own taps instead of sharing them through LDS).  Results are identical in
  * every variant; this only exists so they can be timed against each other in one process.
  * The choice is thread-local (it applies to the calling thread's later calls only). */
 int nqa_set_conv_variant(int variant);

@@ -11,6 +11,10 @@ LIB = os.path.join(HERE, "libnqa_hip.so")
 SOURCES = ["nqa_api.hip", "nqa_conv.hip", "nqa_pool_stats.hip", "nqa_adists.hip", "nqa_prep.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# nqa_adists.hip: the window kernels' tap arithmetic is written as scalar float FMAs with literal-constant weights
+# (v_fmac_f32 with a 32-bit immediate); the SLP vectorizer would pair them into v_pk_*_f32, which issue at half
+# rate on gfx950 and need a {w, w} register pair built per tap
+FILE_FLAGS = {"nqa_adists.hip": ["-fno-slp-vectorize"]}
 
 
 def _stale() -> bool:
@@ -35,7 +39,7 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str |
     procs = []
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", ".o" if not out else "." + os.path.basename(out) + ".o"))
-        cmd = [HIPCC, *FLAGS, *extra_flags, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [HIPCC, *FLAGS, *FILE_FLAGS.get(src, []), *extra_flags, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -23,6 +23,11 @@ namespace nqa {
 static constexpr int kWin = 21;
 static constexpr int kChainBlocks = 1024;  // most blocks per image of the chain's reduction kernels
 
+// tuning hook (nqa_set_conv_variant bit 3): the per-wave-loads form of the window pass, kept for A/B timing
+static thread_local bool g_window_legacy = false;
+void set_adists_window_legacy(bool on) { g_window_legacy = on; }
+static bool adists_window_legacy() { return g_window_legacy; }
+
 struct Gauss {
   float g[kWin];
 };
@@ -341,6 +346,198 @@ __global__ __launch_bounds__(256, 2) void adists_window_lanes_kernel(
   }
 }
 
+// gaussian(21, 7) as ADISTS.py:102-104 builds it (float32(exp(.)) / float32 sum), as compile-time constants:
+// make_gauss() recomputes the taps at run time and adists_run refuses to start if the two disagree.
+// As literals the taps are instruction immediates (v_fmac_f32 / v_mul_f32 with a 32-bit constant): no scalar
+// registers, no broadcast moves -- the packed-float form above kept them in SGPRs, spilled 40-80 of them and
+// built a {w, w} register pair per tap for every v_pk_fma_f32, which on this chip issues at half the rate of
+// v_fma_f32 anyway.
+static constexpr float kG[kWin] = {
+    0x1.8453aep-6f, 0x1.d76892p-6f, 0x1.185a34p-5f, 0x1.46b8bap-5f, 0x1.75117ap-5f, 0x1.a16246p-5f, 0x1.c987c2p-5f,
+    0x1.eb6810p-5f, 0x1.02907ep-4f, 0x1.0a9a20p-4f, 0x1.0d5620p-4f, 0x1.0a9a20p-4f, 0x1.02907ep-4f, 0x1.eb6810p-5f,
+    0x1.c987c2p-5f, 0x1.a16246p-5f, 0x1.75117ap-5f, 0x1.46b8bap-5f, 0x1.185a34p-5f, 0x1.d76892p-6f, 0x1.8453aep-6f};
+
+// the last 21 rows' horizontal sums of the five products, one ring slot per row
+struct WinRing {
+  float s0[kWin], s1[kWin], s2[kWin], s3[kWin], s4[kWin];
+};
+
+// One input row of the separable window: horizontal 21-tap sums of (x, y, x^2, y^2, xy) into ring slot SLOT
+// (a compile-time constant, so the ring stays in registers and is never rotated); when `full`, the vertical
+// 21-tap sums over the ring -- slot s carries weight kG[(20 - SLOT + s) mod 21] at this phase -- and from them
+// the gamma term (ADISTS.py:84-86), T and S (:182-183) of this lane's channel.  Same operations in the same
+// order as the packed form (bit-identical results).
+template <int SLOT>
+__device__ inline void win_row(const float (&x)[kWin], const float (&y)[kWin], WinRing &rg, bool full, float ix,
+                               float iy, float wc, float &gterm, float &tt, float &ss) {
+  float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f, h4 = 0.f;
+#pragma unroll
+  for (int j = 0; j < kWin; ++j) {
+    const float gx = kG[j] * x[j], gy = kG[j] * y[j];
+    h0 += gx;
+    h1 += gy;
+    h2 = fmaf(gx, x[j], h2);
+    h3 = fmaf(gy, y[j], h3);
+    h4 = fmaf(gx, y[j], h4);
+  }
+  rg.s0[SLOT] = h0;
+  rg.s1[SLOT] = h1;
+  rg.s2[SLOT] = h2;
+  rg.s3[SLOT] = h3;
+  rg.s4[SLOT] = h4;
+  if (full) {
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f;
+#pragma unroll
+    for (int sl = 0; sl < kWin; ++sl) {
+      const float wv = kG[(kWin - 1 - SLOT + sl) % kWin];
+      m0 = fmaf(wv, rg.s0[sl], m0);
+      m1 = fmaf(wv, rg.s1[sl], m1);
+      m2 = fmaf(wv, rg.s2[sl], m2);
+      m3 = fmaf(wv, rg.s3[sl], m3);
+      m4 = fmaf(wv, rg.s4[sl], m4);
+    }
+    gterm = div_nr(m2 - m0 * m0, m0 + 1e-12f);
+    const float mx = ix * m0, my = iy * m1;
+    const float vx = ix * ix * m2 - mx * mx, vy = iy * iy * m3 - my * my;
+    const float cov = ix * iy * m4 - mx * my;
+    tt = wc * div_nr(2.f * mx * my + 1e-6f, mx * mx + my * my + 1e-6f);
+    ss = wc * div_nr(2.f * cov + 1e-6f, vx + vy + 1e-6f);
+  }
+}
+
+// The same pass with the taps shared through LDS (the shipped form).  The kernel above lets every wave fetch its
+// own 2 x 21 neighbour pixels per input row from L1: 42 wave-wide loads per output row, of which a block's four
+// adjacent columns share 21 of every 24 pixels -- measured L1/TA-bound, and with workgroups dealt round-robin
+// over the 8 XCDs every pixel was fetched into up to six L2s (rocprofv3: 32 GB fetched for a 4.2 GB tap,
+// L2 hit rate 0.43, the dispatch HBM-bound at 5.6 TB/s).  Here
+//   * workgroup ids are remapped so that the ids that share an XCD (equal mod 8) own a contiguous run of
+//     column groups: neighbouring columns' rows hit one L2 (speed only; any placement is correct);
+//   * a block (4 waves = 4 adjacent output columns) brings each input row's 24-pixel window of both images
+//     into LDS ONCE by LDS-DMA (1-KB pieces, 3 per wave and row instead of 42 loads), three rows ahead of
+//     their use in a four-slot ring, retired by a counted vmcnt + one barrier per row;
+//   * the 42 taps of a wave are ds_read_b32 at immediate offsets from one address register.
+// The arithmetic (horizontal sums, 21-row register ring, vertical sums, T / S / gamma, channel reduction) is
+// the kernel above, instruction for instruction.
+typedef __attribute__((address_space(3))) void lds_void_a_t;
+
+template <typename P, int C>
+__global__ __launch_bounds__(256, 2) void adists_window_lds_kernel(
+    const typename P::T *__restrict__ fx, const typename P::T *__restrict__ fy, int H, int W,
+    const float *__restrict__ q, int B, int ctot, int coff, const float *__restrict__ wgt, Gauss gw,
+    float *__restrict__ gamma, float *__restrict__ tw, float *__restrict__ sw, int nbx, int nby) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  (void)gw;  // the taps are the compile-time constants kG (checked against make_gauss() on the host)
+  typedef typename P::T T;
+  constexpr int SZ = (int)sizeof(T);
+  constexpr int PXB = 64 * SZ;              // one pixel's 64-channel block, bytes
+  constexpr int PPP = 1024 / PXB;           // pixels per 1-KB DMA piece: 4 (float) or 8 (16-bit)
+  constexpr int PPI = SZ == 4 ? 6 : 4;      // pieces per image and row: 24 pixels (float), padded to 32 (16-bit)
+  constexpr int WPX = PPI * PPP;            // window pixels held per image
+  constexpr int NPW = 2 * PPI / 4;          // pieces per wave and row: 3 or 2
+  constexpr int ROWB = 2 * WPX * PXB;       // one ring slot: both images' window of one input row
+  constexpr int D = 3, R = D + 1;           // rows in flight ahead of the one being read; ring slots
+  extern __shared__ __attribute__((aligned(16))) char smem_w[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // XCD-aware decode of the linear workgroup id -> (column group, row strip, image pair)
+  int id = blockIdx.x;
+  {
+    const int nb = gridDim.x, qq = nb >> 3, rr8 = nb & 7, xcd = id & 7, local = id >> 3;
+    id = (xcd < rr8 ? xcd * (qq + 1) : rr8 * (qq + 1) + (xcd - rr8) * qq) + local;
+  }
+  const int bx = id % nbx, by = (id / nbx) % nby, b = id / (nbx * nby);
+  const int Ho = H - (kWin - 1), Wo = W - (kWin - 1);
+  const int ox0 = bx * 4, ox = ox0 + wave;
+  const bool live_col = ox < Wo;            // a dead column computes on clamped pixels and stores nothing
+  const int oy0 = by * 64;
+  const int nout = min(64, Ho - oy0);
+  const int nrows = nout + kWin - 1;
+  const size_t st = (size_t)B * ctot, qo = (size_t)b * ctot + coff;
+  const unsigned img_bytes = (unsigned)H * (unsigned)W * (unsigned)C * (unsigned)SZ;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<T *>(fx + (size_t)b * H * W * C), 0, img_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<T *>(fy + (size_t)b * H * W * C), 0, img_bytes, 0x00020000);
+  // this wave's DMA pieces: piece p = i*4 + wave covers pixels [pidx*PPP, +PPP) of image p / PPI
+  unsigned voff[NPW];  // per-lane source offset of piece i at row 0 of the strip, channel block 0
+  int pdst[NPW], pimg[NPW];
+#pragma unroll
+  for (int i = 0; i < NPW; ++i) {
+    const int pc = i * 4 + wave;
+    pimg[i] = pc / PPI;
+    const int pidx = pc - pimg[i] * PPI;
+    pdst[i] = pimg[i] * (WPX * PXB) + pidx * 1024;
+    const int px = min(ox0 + pidx * PPP + lane / (64 / PPP), W - 1);
+    voff[i] = (unsigned)(((oy0 * W + px) * C) * SZ + (lane % (64 / PPP)) * 16);
+  }
+  const unsigned row_stride = (unsigned)W * (unsigned)C * (unsigned)SZ;
+  const int rd_base = wave * PXB + lane * SZ;  // this lane's tap 0 of image x inside a slot
+  float acc_g = 0.f, acc_t = 0.f, acc_s = 0.f;  // lane l: output row oy0 + l
+  for (int cb = 0; cb < C; cb += 64) {
+    const int c = cb + lane;
+    const float ix = q[0 * st + qo + c], iy = q[1 * st + qo + c], wc = wgt[qo + c];
+    auto issue_row = [&](int r) {
+      char *slot = smem_w + (r % R) * ROWB;
+#pragma unroll
+      for (int i = 0; i < NPW; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(pimg[i] ? ry : rx, (lds_void_a_t *)(slot + pdst[i]), 16,
+                                                 voff[i] + (unsigned)(cb * SZ), (unsigned)r * row_stride, 0, 0);
+    };
+    // every wave has finished reading the previous channel block's last rows before their slots are refilled
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+    for (int r = 0; r < D; ++r)
+      if (r < nrows) issue_row(r);
+    WinRing rg;
+#pragma unroll
+    for (int u = 0; u < kWin; ++u) rg.s0[u] = rg.s1[u] = rg.s2[u] = rg.s3[u] = rg.s4[u] = 0.f;
+    // 21 rows per trip, the row body instantiated once per ring slot: every slot index and every vertical tap
+    // weight is a compile-time constant
+#define NQA_WIN_ROW(SLOT)                                                                                          \
+  {                                                                                                                \
+    const int rr = rr0 + SLOT;                                                                                     \
+    if (rr < nrows) {                                                                                              \
+      /* row rr has landed (this wave's pieces: all but the D-1 younger rows'; everyone's: the barrier), and */   \
+      /* every wave is done with row rr-1, whose slot row rr+D now takes */                                        \
+      if (rr + D <= nrows)                                                                                         \
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((D - 1) * NPW) : "memory");                          \
+      else                                                                                                         \
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");                                              \
+      if (rr + D < nrows) issue_row(rr + D);                                                                       \
+      const char *slot = smem_w + (rr % R) * ROWB + rd_base;                                                       \
+      float xr[kWin], yr[kWin];                                                                                    \
+      _Pragma("unroll") for (int j = 0; j < kWin; ++j) {                                                           \
+        xr[j] = P::to_f(*reinterpret_cast<const T *>(slot + j * PXB));                                             \
+        yr[j] = P::to_f(*reinterpret_cast<const T *>(slot + WPX * PXB + j * PXB));                                 \
+      }                                                                                                            \
+      float gterm = 0.f, tt = 0.f, ss = 0.f;                                                                       \
+      const bool full = rr >= kWin - 1;                                                                            \
+      win_row<SLOT>(xr, yr, rg, full, ix, iy, wc, gterm, tt, ss);                                                  \
+      if (full) {                                                                                                  \
+        const float gs = wave_sum(gterm), ts = wave_sum(tt), sss = wave_sum(ss);                                   \
+        if (lane == rr - (kWin - 1)) {                                                                             \
+          acc_g += gs;                                                                                             \
+          acc_t += ts;                                                                                             \
+          acc_s += sss;                                                                                            \
+        }                                                                                                          \
+      }                                                                                                            \
+    }                                                                                                              \
+  }
+    for (int rr0 = 0; rr0 < nrows; rr0 += kWin) {
+      NQA_WIN_ROW(0) NQA_WIN_ROW(1) NQA_WIN_ROW(2) NQA_WIN_ROW(3) NQA_WIN_ROW(4) NQA_WIN_ROW(5) NQA_WIN_ROW(6)
+      NQA_WIN_ROW(7) NQA_WIN_ROW(8) NQA_WIN_ROW(9) NQA_WIN_ROW(10) NQA_WIN_ROW(11) NQA_WIN_ROW(12) NQA_WIN_ROW(13)
+      NQA_WIN_ROW(14) NQA_WIN_ROW(15) NQA_WIN_ROW(16) NQA_WIN_ROW(17) NQA_WIN_ROW(18) NQA_WIN_ROW(19) NQA_WIN_ROW(20)
+    }
+#undef NQA_WIN_ROW
+  }
+  if (live_col && lane < nout) {
+    const size_t o = ((size_t)b * Ho + oy0 + lane) * Wo + ox;
+    gamma[o] = acc_g / (float)C;
+    tw[o] = acc_t;
+    sw[o] = acc_s;
+  }
+#endif
+}
+
 // The windowed pass of stage 0 (the raw image: 3 float planes, NCHW) in the same shape as the lanes
 // kernel above, with lanes = 64 adjacent output COLUMNS of one plane: every tap load is a coalesced
 // row segment at an immediate offset from one row pointer, the ring and the packed tap arithmetic
@@ -350,6 +547,7 @@ __global__ __launch_bounds__(256, 2) void adists_window_planar_kernel(
     const float *__restrict__ x, const float *__restrict__ y, int H, int W, const float *__restrict__ q, int B,
     int ctot, int coff, const float *__restrict__ wgt, Gauss gw, float *__restrict__ gamma, float *__restrict__ tw,
     float *__restrict__ sw) {
+  (void)gw;  // taps = the compile-time constants kG
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.z;
   const int Ho = H - (kWin - 1), Wo = W - (kWin - 1);
@@ -367,83 +565,45 @@ __global__ __launch_bounds__(256, 2) void adists_window_planar_kernel(
     const float ix = q[0 * st + qo + c], iy = q[1 * st + qo + c], wc = wgt[qo + c];
     const float *px = x + ((size_t)(b * 3 + c) * H + oy0) * W + oxc;
     const float *py = y + ((size_t)(b * 3 + c) * H + oy0) * W + oxc;
-    f32x2 r01[3][7], r23[3][7];
-    float r4[3][7];
+    WinRing rg;
 #pragma unroll
-    for (int g = 0; g < 3; ++g)
-#pragma unroll
-      for (int u = 0; u < 7; ++u) {
-        r01[g][u] = r23[g][u] = (f32x2){0.f, 0.f};
-        r4[g][u] = 0.f;
-      }
-    // 21 rows per trip, fully unrolled: the ring slot (grp*7 + sub) of every row body is a compile-time
-    // constant, so a row's sums drop into their slot without selects and the vertical tap weights are
-    // immediates of the kernel-argument window (no table loads)
-    for (int rr0 = 0; rr0 < nrows; rr0 += 21) {
-#pragma unroll
-      for (int grp = 0; grp < 3; ++grp)
-#pragma unroll
-      for (int sub = 0; sub < 7; ++sub) {
-        const int rr = rr0 + grp * 7 + sub;
-        if (rr < nrows) {
-          float xr[kWin], yr[kWin];
-#pragma unroll
-          for (int j = 0; j < kWin; ++j) {
-            xr[j] = px[j];
-            yr[j] = py[j];
-          }
-          px += W;
-          py += W;
-          __builtin_amdgcn_sched_barrier(0);
-          f32x2 h01 = {0.f, 0.f}, h23 = {0.f, 0.f};
-          float h4 = 0.f;
-#pragma unroll
-          for (int j = 0; j < kWin; ++j) {
-            const f32x2 v = {xr[j], yr[j]};
-            const f32x2 gv = gw.g[j] * v;
-            h01 += gv;
-            h23 = gv * v + h23;
-            h4 = fmaf(gv[0], v[1], h4);
-          }
-          r01[grp][sub] = h01;
-          r23[grp][sub] = h23;
-          r4[grp][sub] = h4;
-          if (rr >= kWin - 1) {
-            f32x2 m01 = {0.f, 0.f}, m23 = {0.f, 0.f};
-            float m4 = 0.f;
-#pragma unroll
-            for (int g = 0; g < 3; ++g)
-#pragma unroll
-              for (int u = 0; u < 7; ++u) {
-                const float wv = gw.g[(kWin - 1 - (grp * 7 + sub) + g * 7 + u) % kWin];  // slot (g,u) at this phase
-                m01 = wv * r01[g][u] + m01;
-                m23 = wv * r23[g][u] + m23;
-                m4 = fmaf(wv, r4[g][u], m4);
-              }
-            const float m0 = m01[0], m1 = m01[1], m2 = m23[0], m3 = m23[1];
-            const float gterm = div_nr(m2 - m0 * m0, m0 + 1e-12f);
-            const float mx = ix * m0, my = iy * m1;
-            const float vx = ix * ix * m2 - mx * mx, vy = iy * iy * m3 - my * my;
-            const float cov = ix * iy * m4 - mx * my;
-            const float tt = wc * div_nr(2.f * mx * my + 1e-6f, mx * mx + my * my + 1e-6f);
-            const float ss = wc * div_nr(2.f * cov + 1e-6f, vx + vy + 1e-6f);
-            if (live) {
-              const size_t o = o0 + (size_t)(rr - (kWin - 1)) * Wo;
-              if (c == 0) {
-                gamma[o] = gterm;
-                tw[o] = tt;
-                sw[o] = ss;
-              } else {
-                const float gsum = gamma[o] + gterm;
-                gamma[o] = c == 2 ? gsum / 3.f : gsum;
-                tw[o] += tt;
-                sw[o] += ss;
-              }
-            }
-          }
-        }
-      }
+    for (int u = 0; u < kWin; ++u) rg.s0[u] = rg.s1[u] = rg.s2[u] = rg.s3[u] = rg.s4[u] = 0.f;
+#define NQA_PLANAR_ROW(SLOT)                                                          \
+  {                                                                                   \
+    const int rr = rr0 + SLOT;                                                        \
+    if (rr < nrows) {                                                                 \
+      float xr[kWin], yr[kWin];                                                       \
+      _Pragma("unroll") for (int j = 0; j < kWin; ++j) {                              \
+        xr[j] = px[j];                                                                \
+        yr[j] = py[j];                                                                \
+      }                                                                               \
+      px += W;                                                                        \
+      py += W;                                                                        \
+      float gterm = 0.f, tt = 0.f, ss = 0.f;                                          \
+      const bool full = rr >= kWin - 1;                                               \
+      win_row<SLOT>(xr, yr, rg, full, ix, iy, wc, gterm, tt, ss);                     \
+      if (full && live) {                                                             \
+        const size_t o = o0 + (size_t)(rr - (kWin - 1)) * Wo;                         \
+        if (c == 0) {                                                                 \
+          gamma[o] = gterm;                                                           \
+          tw[o] = tt;                                                                 \
+          sw[o] = ss;                                                                 \
+        } else {                                                                      \
+          const float gsum = gamma[o] + gterm;                                        \
+          gamma[o] = c == 2 ? gsum / 3.f : gsum;                                      \
+          tw[o] += tt;                                                                \
+          sw[o] += ss;                                                                \
+        }                                                                             \
+      }                                                                               \
+    }                                                                                 \
+  }
+    for (int rr0 = 0; rr0 < nrows; rr0 += kWin) {
+      NQA_PLANAR_ROW(0) NQA_PLANAR_ROW(1) NQA_PLANAR_ROW(2) NQA_PLANAR_ROW(3) NQA_PLANAR_ROW(4) NQA_PLANAR_ROW(5)
+      NQA_PLANAR_ROW(6) NQA_PLANAR_ROW(7) NQA_PLANAR_ROW(8) NQA_PLANAR_ROW(9) NQA_PLANAR_ROW(10) NQA_PLANAR_ROW(11)
+      NQA_PLANAR_ROW(12) NQA_PLANAR_ROW(13) NQA_PLANAR_ROW(14) NQA_PLANAR_ROW(15) NQA_PLANAR_ROW(16) NQA_PLANAR_ROW(17)
+      NQA_PLANAR_ROW(18) NQA_PLANAR_ROW(19) NQA_PLANAR_ROW(20)
     }
+#undef NQA_PLANAR_ROW
   }
 }
 
@@ -859,9 +1019,33 @@ static int launch_window_lanes(const void *fx, const void *fy, int B, int H, int
                                int coff, const float *wgt, const Gauss &g, float *gamma, float *tw, float *sw,
                                hipStream_t st) {
   const int Ho = H - (kWin - 1), Wo = W - (kWin - 1);
+  const typename P::T *px = reinterpret_cast<const typename P::T *>(fx), *py = reinterpret_cast<const typename P::T *>(fy);
+  // the shipped form for float taps (f32 / f32s): taps shared through LDS, XCD-aware column order.  16-bit taps
+  // (the opt-in f16 / bf16 modes) measured 20 % slower that way (2-byte LDS reads + conversions) and keep the first form
+  if (!adists_window_legacy() && sizeof(typename P::T) == 4) {
+    constexpr int LDS = 4 * 2 * ((int)sizeof(typename P::T) == 4 ? 24 : 32) * 64 * (int)sizeof(typename P::T);
+    const int nbx = cdiv(Wo, 4), nby = cdiv(Ho, 64);
+    const long nblk = (long)nbx * nby * B;
+    if (nblk > 0x7FFFFFFFL) {
+      set_error("adists_window: grid too large");
+      return NQA_E_SHAPE;
+    }
+    TimedLaunch t(NQA_K_ADISTS, st);
+#define NQA_WIN(CC)                                                                                                  \
+  adists_window_lds_kernel<P, CC><<<(unsigned)nblk, 256, LDS, st>>>(px, py, H, W, q, B, ctot, coff, wgt, g, gamma, \
+                                                                    tw, sw, nbx, nby)
+    switch (C) {
+      case 64: NQA_WIN(64); break;
+      case 128: NQA_WIN(128); break;
+      case 256: NQA_WIN(256); break;
+      case 512: NQA_WIN(512); break;
+      default: set_error("adists_window: unsupported channel count %d", C); return NQA_E_SHAPE;
+    }
+#undef NQA_WIN
+    return check_launch("adists_window_lds");
+  }
   dim3 grid(cdiv(Wo, 4), cdiv(Ho, 64), B);
   TimedLaunch t(NQA_K_ADISTS, st);
-  const typename P::T *px = reinterpret_cast<const typename P::T *>(fx), *py = reinterpret_cast<const typename P::T *>(fy);
   switch (C) {
     case 64: adists_window_lanes_kernel<P, 64><<<grid, 256, 0, st>>>(px, py, H, W, q, B, ctot, coff, wgt, g, gamma, tw, sw); break;
     case 128: adists_window_lanes_kernel<P, 128><<<grid, 256, 0, st>>>(px, py, H, W, q, B, ctot, coff, wgt, g, gamma, tw, sw); break;
@@ -991,6 +1175,12 @@ static int adists_run(const float *x, const float *y, int B, int H, int W, const
   }
   // ---- heavy pass: gamma / TW / SW maps per stage ----
   static const Gauss gauss = make_gauss();
+  for (int i = 0; i < kWin; ++i)
+    if (gauss.g[i] != kG[i]) {
+      set_error("adists_forward: this host's exp() gives a different Gaussian window than the kernels' constants "
+                "(tap %d: %a vs %a)", i, (double)gauss.g[i], (double)kG[i]);
+      return NQA_E_LAUNCH;
+    }
   for (int k = 0; k < 6; ++k) {
     float *gamma = reinterpret_cast<float *>(base + p.maps[k][0]);
     float *tw = reinterpret_cast<float *>(base + p.maps[k][1]);

@@ -3,6 +3,7 @@
 usage: python tools/gpu_layer_bench.py [256|1080]   (NQA_LIB selects an ablation build)
 Variants are interleaved per layer in one process after a global warm-up (DVFS).
 """
+import os
 import sys
 
 import torch
@@ -13,12 +14,11 @@ from nerf_qa_amd import ops, synth  # noqa: E402
 dev = torch.device("cuda:0")
 which = sys.argv[1] if len(sys.argv) > 1 else "256"
 H, W, N = (256, 256, 64) if which == "256" else (1080, 1920, 8)
-import os
 prec = os.environ.get("NQA_TOOL_PREC", "f16")
 DT = {"f16": torch.float16, "bf16": torch.bfloat16}.get(prec, torch.float32)
 packed = ops.pack_vgg_weights(synth.vgg16_weights(1234), prec).to(dev)
 dims = ops.pyramid_dims(H, W)
-VARIANTS = (0, 1, 2)
+VARIANTS = tuple(int(v) for v in os.environ.get('NQA_TOOL_VARIANTS', '0,1,2').split(','))
 
 
 def time_layer(a, layer, reps):
