@@ -70,6 +70,17 @@ size_t layer_offset(int layer, int prec) {
   return o;
 }
 size_t layer0_mfma_offset(int prec) { return layer_offset(0, prec) + align_up(27 * 64 * 4 + 64 * 4, 256); }
+// Register-resident weight fragments of the 64-input-channel layers (conv1_2 = layer 1, conv2_1 = layer 2), 16-bit
+// modes only: the whole layer as 16x16x32 MFMA A fragments [cout/32][2 tiles of 16][18 k-steps][64 lanes][8 halfs],
+// k-step = chunk * 9 + tap (chunk = 32 input channels), lane = (row l15, k-group c4): element j is
+// w[cout = 32*g + 16*i + l15][cin = 32*chunk + 8*c4 + j][tap].  conv3x3_regw_kernel loads its 2 x 18 fragments
+// (144 VGPRs) once per persistent block.  Appended behind the ordinary layers.
+size_t regw_bytes(int layer) { return (size_t)kConvs[layer].cout * 64 * 9 * 2; }
+size_t regw_offset(int layer, int prec) {
+  size_t o = layer_offset(NQA_NUM_CONVS, prec);
+  if (layer == 2) o += regw_bytes(1);
+  return o;
+}
 size_t layer_bias_offset(int layer, int prec) {
   const ConvSpec &c = kConvs[layer];
   if (layer == 0) return layer_offset(0, prec) + 27 * 64 * 4;
@@ -289,7 +300,11 @@ int nqa_timing_collect(int launches[NQA_K_COUNT], double ms[NQA_K_COUNT]) {
   return NQA_OK;
 }
 
-size_t nqa_packed_weights_bytes(int prec) { return layer_offset(NQA_NUM_CONVS, prec); }
+size_t nqa_packed_weights_bytes(int prec) {
+  size_t n = layer_offset(NQA_NUM_CONVS, prec);
+  if (prec_valid(prec) && prec_elem_bytes(prec) == 2) n += regw_bytes(1) + regw_bytes(2);
+  return n;
+}
 
 int nqa_pack_vgg_weights(const float *const w_host[NQA_NUM_CONVS], const float *const b_host[NQA_NUM_CONVS], int prec,
                          void *packed_host) {
@@ -383,6 +398,22 @@ int nqa_pack_vgg_weights(const float *const w_host[NQA_NUM_CONVS], const float *
               }
             }
     memcpy(blob + layer_bias_offset(l, prec), b_host[l], (size_t)cs.cout * 4);
+  }
+  if (prec_elem_bytes(prec) == 2) {
+    for (int l = 1; l <= 2; ++l) {
+      const ConvSpec &cs = kConvs[l];
+      uint16_t *dst = reinterpret_cast<uint16_t *>(blob + regw_offset(l, prec));
+      for (int g = 0; g < cs.cout / 32; ++g)
+        for (int i = 0; i < 2; ++i)
+          for (int ks = 0; ks < 18; ++ks)
+            for (int lane = 0; lane < 64; ++lane)
+              for (int j = 0; j < 8; ++j) {
+                const int cout = 32 * g + 16 * i + (lane & 15), cin = 32 * (ks / 9) + 8 * (lane >> 4) + j, t = ks % 9;
+                const float v = w_host[l][((size_t)cout * cs.cin + cin) * 9 + t];
+                dst[((((size_t)g * 2 + i) * 18 + ks) * 64 + lane) * 8 + j] =
+                    prec == NQA_PREC_BF16 ? f32_to_bf16(v) : f32_to_f16(v);
+              }
+    }
   }
   return NQA_OK;
 }

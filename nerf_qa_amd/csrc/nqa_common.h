@@ -142,6 +142,8 @@ size_t layer_bias_offset(int layer, int prec);
 // conv1_1 again as 16-bit MFMA A fragments [ky][cout][h][8], k = ky*16 + kx*4 + c (zero for
 // kx = 3 or c = 3), 6144 bytes, for the fused stage-1 kernel (zeros in the f32 blob)
 size_t layer0_mfma_offset(int prec);
+// 16x16x32 MFMA A fragments of a 64-input-channel layer (1 or 2), 16-bit modes: see nqa_api.hip
+size_t regw_offset(int layer, int prec);
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -604,6 +604,188 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void conv3x3_igemm_kernel(
 }
 
 // ---------------------------------------------------------------------------------
+// conv3x3 of a 64-input-channel layer with the WEIGHTS IN REGISTERS (16-bit modes; conv2_1 = layer 2).
+// ---------------------------------------------------------------------------------
+// With Cin = 64 the contraction is only 18 k-steps of 32 and the implicit-GEMM kernel above spends most of a
+// stage behind its barrier (6 stages per tile, each shorter than an LDS-DMA round trip; measured 0.34 of the
+// MFMA peak).  Here nothing is staged per k-step at all:
+//   * a wave owns 32 output channels and keeps their 32 x 576 weights as 2 x 18 MFMA A fragments in 144 VGPRs
+//     for the life of a persistent block (one block of 8 waves per CU: NCG = Cout/32 channel groups times
+//     8/NCG pixel parts of an 8 x 32-pixel tile);
+//   * the only thing that moves is the activation: the tile's 10 x 34 halo patch (both 32-channel chunks,
+//     42.5 KB) arrives by LDS-DMA into a three-slot ring two tiles ahead of its use; ONE barrier per tile
+//     publishes it.  Out-of-image halo cells are zeroed explicitly per tile (the conv's zero padding);
+//   * per k-step a wave reads 4 pixel fragments (16 px x 32 ch, one ds_read_b128 each) and feeds each to its
+//     two weight tiles: 0.5 LDS reads per v_mfma_f32_16x16x32, half of what the LDS can deliver;
+//   * bias + ReLU in registers, results leave as 8-byte buffer stores (4 consecutive channels of a pixel);
+//     out-of-image pixels get an out-of-range offset, so every wave issues the same number of stores and of
+//     DMA pieces per tile and the ring is retired with ONE counted vmcnt per tile (stores and DMA count
+//     together, in issue order).
+// Tiles are dealt XCD-aware: the workgroups that share an L2 walk a contiguous range of tiles.
+template <typename P, int NCG>
+__global__ __launch_bounds__(512) void conv3x3_regw_kernel(const typename P::T *__restrict__ in,
+                                                           const char *__restrict__ wreg,
+                                                           const float *__restrict__ bias,
+                                                           typename P::T *__restrict__ out, int H, int W, int tiles_x,
+                                                           int tiles_y, int total_tiles) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef typename P::T T;
+  constexpr int COUT = 32 * NCG, TH = 8, TW = 32, HWD = TW + 2, NQ = (TH + 2) * HWD;  // 340 halo pixels
+  constexpr int CH_ITEMS = 1536, CH_BYTES = CH_ITEMS * 16, SLOT = 2 * CH_BYTES;       // 3 DMA rounds per chunk
+  constexpr int NPIECE = 6;                        // DMA pieces per wave and tile
+  constexpr int RW = NCG;                          // tile rows per wave (8 rows over 8/NCG pixel parts)
+  constexpr int GPP = 2;                           // 16-pixel groups per pass (one 32-pixel tile row)
+  constexpr int NPASS = 2 * RW / GPP;              // passes per wave and tile
+  constexpr int NSTORE = 2 * GPP * NPASS;          // buffer stores per wave and tile
+  static_assert(NCG == 2 || NCG == 4, "64 or 128 output channels");
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // three halo slots
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, c4 = lane >> 4;
+  const int cg = wave % NCG, ph = wave / NCG;
+
+  // ---- this block's tiles: XCD x owns tiles [T*x/8, T*(x+1)/8), dealt round-robin to its blocks ----
+  const int nblk = gridDim.x, nx = nblk < 8 ? nblk : 8;  // (a grid of fewer than 8 blocks has fewer classes)
+  const int xcd = blockIdx.x % nx, jb = blockIdx.x / nx;
+  const int blk_per_xcd = (nblk - xcd + nx - 1) / nx;  // blocks with id = xcd (mod nx)
+  const int t_lo = (int)((long)total_tiles * xcd / nx), t_hi = (int)((long)total_tiles * (xcd + 1) / nx);
+  const int my_tiles = t_lo + jb < t_hi ? (t_hi - t_lo - jb - 1) / blk_per_xcd + 1 : 0;
+  if (my_tiles == 0) return;  // (block-uniform)
+  auto tile_coords = [&](int it, int &n, int &x0, int &y0) {
+    const int t = t_lo + jb + it * blk_per_xcd;
+    n = t / (tiles_x * tiles_y);
+    const int t2 = t - n * (tiles_x * tiles_y), by = t2 / tiles_x;
+    x0 = (t2 - by * tiles_x) * TW;
+    y0 = by * TH;
+  };
+
+  // ---- weights: 2 tiles of 16 channels x 18 k-steps, straight into registers ----
+  u32x4 wf[2][18];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int ks = 0; ks < 18; ++ks)
+      wf[i][ks] = *reinterpret_cast<const u32x4 *>(wreg + ((((size_t)cg * 2 + i) * 18 + ks) * 64 + lane) * 16);
+  float bia[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bia[i][e] = bias[cg * 32 + i * 16 + 4 * c4 + e];
+
+  // ---- halo DMA plan: item j (16 B) of a chunk = quarter (j&3)^swz(q) of halo pixel q = j>>2; rounds r and r+3
+  // are the two chunks of the same (pixel, quarter) ----
+  int p_hy[3], p_hx[3], p_c[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const int j = r * 512 + tid, q = j >> 2;
+    p_c[r] = (j & 3) ^ lds_swz<true>(q);
+    p_hy[r] = q < NQ ? q / HWD : -100000;  // items past the patch: never inside any image
+    p_hx[r] = q - (q / HWD) * HWD;
+  }
+  const unsigned kOOB = 0x80000000u;
+  const unsigned img_in_bytes = (unsigned)H * (unsigned)W * 64u * (unsigned)sizeof(T);
+  const unsigned img_out_bytes = (unsigned)H * (unsigned)W * (unsigned)COUT * (unsigned)sizeof(T);
+  auto issue_halo = [&](int it, int slot_idx) {
+    char *slot = smem + slot_idx * SLOT;
+    const bool real = it < my_tiles;  // past the last tile: same number of pieces, all out of range
+    int n = 0, x0 = 0, y0 = 0;
+    if (real) tile_coords(it, n, x0, y0);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T *>(in + (size_t)n * H * W * 64), 0, img_in_bytes, 0x00020000);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int gy = y0 - 1 + p_hy[r], gx = x0 - 1 + p_hx[r];
+      const bool ok = real && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      const unsigned off = ok ? (unsigned)(((gy * W + gx) * 64 + p_c[r] * 8) * (int)sizeof(T)) : kOOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t *)(slot + r * 8192 + wave * 1024), 16, off, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t *)(slot + CH_BYTES + r * 8192 + wave * 1024), 16,
+                                               off, 64, 0, 0);
+      if (real && !ok && p_hy[r] >= 0) {  // zero padding (the DMA transfers nothing for an out-of-range lane)
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        *reinterpret_cast<u32x4 *>(slot + (r * 512 + tid) * 16) = z;
+        *reinterpret_cast<u32x4 *>(slot + CH_BYTES + (r * 512 + tid) * 16) = z;
+      }
+    }
+  };
+
+  issue_halo(0, 0);
+  issue_halo(1, 1);
+  for (int it = 0; it < my_tiles; ++it) {
+    int n, x0, y0;
+    tile_coords(it, n, x0, y0);
+    // the halo of tile `it` has landed: in issue order the only younger operations are the previous tile's
+    // stores and the next tile's 6 pieces (always issued, see issue_halo)
+    if (it == 0)
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NPIECE) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NPIECE + NSTORE) : "memory");
+    const char *slot = smem + (it % 3) * SLOT;
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+        out + (size_t)n * H * W * COUT, 0, img_out_bytes, 0x00020000);
+#pragma unroll 1
+    for (int pass = 0; pass < NPASS; ++pass) {
+      int q0[GPP];  // halo pixel of this lane's output pixel at tap (0,0), per 16-pixel group
+#pragma unroll
+      for (int g = 0; g < GPP; ++g) q0[g] = (ph * RW + pass) * HWD + g * 16 + l15;
+      // opaque per pass: otherwise hipcc hoists the 72 fragment addresses of the unrolled k loop out of the
+      // persistent tile loop and spills the weight registers
+      asm volatile("" : "+v"(q0[0]), "+v"(q0[1]));
+      f32x4 acc[2][GPP];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < GPP; ++g) acc[i][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      u32x4 bf[2][GPP];
+      auto load_b = [&](int ks, u32x4(&b)[GPP]) {
+        const int cc = ks / 9, t = ks - cc * 9, ky = t / 3, kx = t - ky * 3;
+#pragma unroll
+        for (int g = 0; g < GPP; ++g) {
+          const int q = q0[g] + ky * HWD + kx;
+          b[g] = *reinterpret_cast<const u32x4 *>(slot + cc * CH_BYTES + q * 64 + ((c4 ^ lds_swz<true>(q)) << 4));
+        }
+      };
+      load_b(0, bf[0]);
+#pragma unroll
+      for (int ks = 0; ks < 18; ++ks) {
+        if (ks + 1 < 18) load_b(ks + 1, bf[(ks + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < GPP; ++g)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            if constexpr (P::ID == NQA_PREC_BF16)
+              acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[i][ks]),
+                                                                  __builtin_bit_cast(bf16x8, bf[ks & 1][g]), acc[i][g], 0, 0, 0);
+            else
+              acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wf[i][ks]),
+                                                                 __builtin_bit_cast(f16x8, bf[ks & 1][g]), acc[i][g], 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // bias + ReLU; lane = (pixel l15 of the group, channels 4*c4.. of each 16-channel tile): 8-byte stores
+#pragma unroll
+      for (int g = 0; g < GPP; ++g) {
+        const int gy = y0 + ph * RW + pass, gx = x0 + g * 16 + l15;
+        const bool inside = gy < H && gx < W;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          typedef __attribute__((ext_vector_type(4))) T t4;
+          t4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = P::from_f(fmaxf(acc[i][g][e] + bia[i][e], 0.f));
+          const unsigned off =
+              inside ? (unsigned)(((gy * W + gx) * COUT + cg * 32 + i * 16 + 4 * c4) * (int)sizeof(T)) : kOOB;
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), orsrc, off, 0, 0);
+        }
+      }
+    }
+    // slot (it+2)%3 was last read during tile it-1, which every wave left before this tile's barrier
+    issue_halo(it + 2, (it + 2) % 3);
+  }
+#endif
+}
+
+// ---------------------------------------------------------------------------------
 // conv1_1 + conv1_2 fused (16-bit modes): the whole of stage 1 without the 64-channel
 // full-resolution intermediate ever touching HBM.
 // ---------------------------------------------------------------------------------
@@ -1222,6 +1404,38 @@ static int launch_igemm(const void *in, int n, int H, int W, int cin, int cout, 
   return check_launch("conv3x3_igemm");
 }
 
+// compute units of the current device (cached per device: a process may drive several)
+static int num_cus();
+
+// conv2_1 (64 -> 128) with register-resident weights, 16-bit modes; persistent, one 8-wave block per CU
+template <typename P>
+static int launch_regw(const void *in, int n, int H, int W, int layer, const char *packed, void *out, hipStream_t st) {
+  constexpr int LDS = 3 * 2 * 1536 * 16;
+  static bool attr_done_dev[64] = {false};
+  bool &attr_done = attr_done_dev[current_device() & 63];
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_regw_kernel<P, 4>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+      set_error("conv3x3_regw: cannot raise the dynamic LDS limit to %d bytes", LDS);
+      return NQA_E_LAUNCH;
+    }
+    attr_done = true;
+  }
+  const int cus = num_cus();
+  if (!cus) {
+    set_error("conv3x3_regw: cannot query the device");
+    return NQA_E_LAUNCH;
+  }
+  const int tiles_x = cdiv(W, 32), tiles_y = cdiv(H, 8), total = n * tiles_x * tiles_y;
+  const int grid = total < cus ? total : cus;
+  const float *bias = reinterpret_cast<const float *>(packed + layer_bias_offset(layer, P::ID));
+  TimedLaunch t(NQA_K_CONV, st);
+  conv3x3_regw_kernel<P, 4><<<grid, 512, LDS, st>>>(reinterpret_cast<const typename P::T *>(in),
+                                                    packed + regw_offset(layer, P::ID), bias,
+                                                    reinterpret_cast<typename P::T *>(out), H, W, tiles_x, tiles_y, total);
+  return check_launch("conv3x3_regw");
+}
+
 template <typename P>
 static int launch_conv(const void *in, int n, int H, int W, int layer, const char *packed, void *out, hipStream_t st) {
   const ConvSpec &cs = kConvs[layer];
@@ -1263,6 +1477,7 @@ static int launch_conv(const void *in, int n, int H, int W, int layer, const cha
     if (wide) return launch_igemm<P, 2, 4, 2, 4, 32>(in, n, H, W, cs.cin, cs.cout, wpk, bias, out, out_split, st);
   }
   if constexpr (sizeof(typename P::T) == 2) {
+    if (layer == 2 && !(g_ring3 & 1) && W >= 16) return launch_regw<P>(in, n, H, W, layer, packed, out, st);
     if ((g_ring3 & 2) && cs.cout == 128 && !narrow)  // 128 ch x 256 px, 8 waves, three-deep weight ring
       return launch_igemm<P, 2, 4, 2, 2, 32, true, 3>(in, n, H, W, cs.cin, cs.cout, wpk, bias, out, out_split, st);
     if ((g_ring3 & 1) && !big) {  // 128 ch x 128 px, 4 waves, three-deep weight ring
