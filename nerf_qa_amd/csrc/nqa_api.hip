@@ -76,6 +76,10 @@ size_t layer0_mfma_offset(int prec) { return layer_offset(0, prec) + align_up(27
 // w[cout = 32*g + 16*i + l15][cin = 32*chunk + 8*c4 + j][tap].  conv3x3_regw_kernel loads its 2 x 18 fragments
 // (144 VGPRs) once per persistent block.  Appended behind the ordinary layers.
 size_t regw_bytes(int layer) { return (size_t)kConvs[layer].cout * 64 * 9 * 2; }
+// conv1_1 as 16x16x32 MFMA A fragments for conv1_regw_kernel: [4 tiles of 16 channels][2 MFMAs][64 lanes][8 halfs];
+// MFMA m contracts kernel rows 2m and 2m+1: k = 16*(ky - 2m) + 4*kx + c (kx, c padded to 4; zero for ky = 3)
+static constexpr size_t kW1M16Bytes = 4 * 2 * 64 * 16;
+size_t layer0_m16_offset(int prec) { return layer_offset(NQA_NUM_CONVS, prec) + regw_bytes(1) + regw_bytes(2); }
 size_t regw_offset(int layer, int prec) {
   size_t o = layer_offset(NQA_NUM_CONVS, prec);
   if (layer == 2) o += regw_bytes(1);
@@ -302,7 +306,7 @@ int nqa_timing_collect(int launches[NQA_K_COUNT], double ms[NQA_K_COUNT]) {
 
 size_t nqa_packed_weights_bytes(int prec) {
   size_t n = layer_offset(NQA_NUM_CONVS, prec);
-  if (prec_valid(prec) && prec_elem_bytes(prec) == 2) n += regw_bytes(1) + regw_bytes(2);
+  if (prec_valid(prec) && prec_elem_bytes(prec) == 2) n += regw_bytes(1) + regw_bytes(2) + kW1M16Bytes;
   return n;
 }
 
@@ -414,6 +418,16 @@ int nqa_pack_vgg_weights(const float *const w_host[NQA_NUM_CONVS], const float *
                     prec == NQA_PREC_BF16 ? f32_to_bf16(v) : f32_to_f16(v);
               }
     }
+    uint16_t *w1 = reinterpret_cast<uint16_t *>(blob + layer0_m16_offset(prec));
+    for (int i = 0; i < 4; ++i)
+      for (int m = 0; m < 2; ++m)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 8; ++j) {
+            const int k = 8 * (lane >> 4) + j, ky = 2 * m + (k >> 4), kx = (k >> 2) & 3, c = k & 3;
+            const int cout = 16 * i + (lane & 15);
+            const float v = (ky < 3 && kx < 3 && c < 3) ? w_host[0][(cout * 3 + c) * 9 + ky * 3 + kx] : 0.f;
+            w1[(((size_t)i * 2 + m) * 64 + lane) * 8 + j] = prec == NQA_PREC_BF16 ? f32_to_bf16(v) : f32_to_f16(v);
+          }
   }
   return NQA_OK;
 }

@@ -144,6 +144,7 @@ size_t layer_bias_offset(int layer, int prec);
 size_t layer0_mfma_offset(int prec);
 // 16x16x32 MFMA A fragments of a 64-input-channel layer (1 or 2), 16-bit modes: see nqa_api.hip
 size_t regw_offset(int layer, int prec);
+size_t layer0_m16_offset(int prec);  // conv1_1 as 16x16x32 A fragments (16-bit modes)
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -735,6 +735,8 @@ __global__ __launch_bounds__(512) void conv3x3_regw_kernel(const typename P::T *
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int g = 0; g < GPP; ++g) acc[i][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      // pixel fragments of k-step ks+1 are read while the MFMAs of ks run (two register sets; a third set, two steps
+      // of lead, measured 10 % SLOWER on conv2_1)
       u32x4 bf[2][GPP];
       auto load_b = [&](int ks, u32x4(&b)[GPP]) {
         const int cc = ks / 9, t = ks - cc * 9, ky = t / 3, kx = t - ky * 3;
@@ -781,6 +783,272 @@ __global__ __launch_bounds__(512) void conv3x3_regw_kernel(const typename P::T *
     }
     // slot (it+2)%3 was last read during tile it-1, which every wave left before this tile's barrier
     issue_halo(it + 2, (it + 2) % 3);
+  }
+#endif
+}
+
+// ---------------------------------------------------------------------------------
+// Stage 1 (conv1_1 + conv1_2) on the same principle, 16-bit modes: the shipped form.
+// ---------------------------------------------------------------------------------
+// conv1_2 is conv3x3_regw_kernel with NCG = 2 (a wave = 32 of the 64 output channels x 2 rows of an 8 x 32 tile,
+// its 2 x 18 weight fragments in registers), but its halo patch is not loaded: relu1_1 never exists in HBM.  Per
+// tile the block
+//   1. fetches the 12 x 36 raw pixels under the 10 x 34 halo patch (3 float planes -> one thread per pixel, loads
+//      issued before the previous tile's conv1_2 so that they land under its MFMAs), normalises them
+//      ((x-mean)/std, zero outside the image = conv1_1's padding) into an LDS patch of [row][col][4 halfs];
+//   2. runs conv1_1 for the 340 halo pixels on the matrix cores: with the contraction ordered
+//      k = 16*ky + 4*kx + c (kx and c padded to 4) a lane's 8-element B fragment is 16 contiguous bytes of that
+//      patch, so one 16-pixel x 16-channel tile is two v_mfma_16x16x32 (kernel rows 0-1, then row 2 + zeros);
+//      bias + ReLU, zero outside the image (conv1_2's padding), stored as halfs straight into the swizzled
+//      [chunk][pixel][64 B] halo image conv1_2 reads (22 groups of 16 pixels over the 8 waves);
+//   3. conv1_2 from that image, bias + ReLU, 8-byte stores.
+// Two halo images alternate; two barriers per tile (patch visible, halo visible).  conv1_1 is 6 % of the FLOPs
+// and costs the waves ~15 % of a tile here (it is not overlapped with conv1_2 of another wave group as in
+// conv1_fused_kernel below), against conv1_2 running at 0.5 LDS reads per MFMA instead of 1.5.
+template <typename P>
+__global__ __launch_bounds__(512) void conv1_regw_kernel(const float *__restrict__ x, const float *__restrict__ y, int B,
+                                                         const char *__restrict__ w1m, const float *__restrict__ bias1,
+                                                         const char *__restrict__ wreg, const float *__restrict__ bias2,
+                                                         typename P::T *__restrict__ out, int H, int W, int tiles_x,
+                                                         int tiles_y, int total_tiles) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef typename P::T T;
+  typedef __attribute__((ext_vector_type(4))) T t4;
+  constexpr int NCG = 2, COUT = 64, TH = 8, TW = 32, HWD = TW + 2, NQ = (TH + 2) * HWD;  // 340 halo pixels
+  constexpr int CH_BYTES = 1536 * 16, SLOT = 2 * CH_BYTES;
+  constexpr int RAWP = 40, RAW_ROWS = 13, RAW_BYTES = RAW_ROWS * RAWP * 8;  // (+1 row read, with zero weights, by MFMA 1)
+  constexpr int RAW_OFF = 2 * SLOT, W1_OFF = RAW_OFF + 2 * RAW_BYTES, B1_OFF = W1_OFF + 4 * 2 * 64 * 16;  // two raw patches
+  constexpr int RW = NCG, GPP = 2, NPASS = 2 * RW / GPP;
+  constexpr int NGRP = (NQ + 15) / 16;  // 22 groups of 16 halo pixels
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [halo 0][halo 1][raw 0][raw 1][conv1_1 fragments][bias1]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, c4 = lane >> 4;
+  const int cg = wave % NCG, ph = wave / NCG;
+  const int HW = H * W;
+
+  const int nblk = gridDim.x, nx = nblk < 8 ? nblk : 8;
+  const int xcd = blockIdx.x % nx, jb = blockIdx.x / nx;
+  const int blk_per_xcd = (nblk - xcd + nx - 1) / nx;
+  const int t_lo = (int)((long)total_tiles * xcd / nx), t_hi = (int)((long)total_tiles * (xcd + 1) / nx);
+  const int my_tiles = t_lo + jb < t_hi ? (t_hi - t_lo - jb - 1) / blk_per_xcd + 1 : 0;
+  if (my_tiles == 0) return;  // (block-uniform)
+  auto tile_coords = [&](int it, int &n, int &x0, int &y0) {
+    const int t = t_lo + jb + it * blk_per_xcd;
+    n = t / (tiles_x * tiles_y);
+    const int t2 = t - n * (tiles_x * tiles_y), by = t2 / tiles_x;
+    x0 = (t2 - by * tiles_x) * TW;
+    y0 = by * TH;
+  };
+
+  // ---- one-time: conv1_2 weights into registers; conv1_1 fragments, bias1 and a zeroed raw patch into LDS ----
+  u32x4 wf[2][18];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int ks = 0; ks < 18; ++ks)
+      wf[i][ks] = *reinterpret_cast<const u32x4 *>(wreg + ((((size_t)cg * 2 + i) * 18 + ks) * 64 + lane) * 16);
+  float bia[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bia[i][e] = bias2[cg * 32 + i * 16 + 4 * c4 + e];
+  reinterpret_cast<u32x4 *>(smem + W1_OFF)[tid] = reinterpret_cast<const u32x4 *>(w1m)[tid];  // 8 KB = 512 x 16 B
+  if (tid < 64) reinterpret_cast<float *>(smem + B1_OFF)[tid] = bias1[tid];
+  for (int i = tid; i < 2 * RAW_BYTES / 8; i += 512) reinterpret_cast<u32x2 *>(smem + RAW_OFF)[i] = (u32x2){0u, 0u};
+
+  // ---- raw patch: thread t < 432 owns pixel (t / 36, t % 36) of the 12 x 36 patch ----
+  const int r_row = tid / 36, r_col = tid - r_row * 36;
+  const bool r_mine = tid < 12 * 36;
+  const float mean[3] = {0.485f, 0.456f, 0.406f};
+  const float sd[3] = {0.229f, 0.224f, 0.225f};
+  float rv[3];
+  bool r_ok = false;
+  auto raw_fetch = [&](int it) {
+    r_ok = false;
+    rv[0] = rv[1] = rv[2] = 0.f;
+    if (it < my_tiles && r_mine) {
+      int n, x0, y0;
+      tile_coords(it, n, x0, y0);
+      const int gy = y0 - 2 + r_row, gx = x0 - 2 + r_col;
+      r_ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      if (r_ok) {
+        const float *img = (n < B ? x + (size_t)n * 3 * HW : y + (size_t)(n - B) * 3 * HW) + gy * W + gx;
+        rv[0] = img[0];
+        rv[1] = img[HW];
+        rv[2] = img[2 * HW];
+      }
+    }
+  };
+  auto raw_commit = [&](int buf) {
+    if (r_mine) {
+      t4 v;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) v[c] = P::from_f(r_ok ? (rv[c] - mean[c]) / sd[c] : 0.f);
+      v[3] = P::from_f(0.f);
+      *reinterpret_cast<t4 *>(smem + RAW_OFF + buf * RAW_BYTES + (r_row * RAWP + r_col) * 8) = v;
+    }
+  };
+  // ---- conv1_1 of tile `it` (raw patch it&1) into halo image it&1: all waves, groups wave, wave+8, wave+16 in
+  // flight together (three independent read -> MFMA -> write chains instead of one after the other) ----
+  auto conv1_1_halo = [&](int it) {
+    int n, x0, y0;
+    tile_coords(it, n, x0, y0);
+    char *slot = smem + (it & 1) * SLOT;
+    const char *rawp = smem + RAW_OFF + (it & 1) * RAW_BYTES;
+    constexpr int NU = (NGRP + 7) / 8;  // 3
+    f32x4 a1[NU][4];
+    int qv[NU], hyv[NU], hxv[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int q = (wave + 8 * u) * 16 + l15, qc = q < NQ ? q : NQ - 1;
+      qv[u] = q;
+      hyv[u] = qc / HWD;
+      hxv[u] = qc - hyv[u] * HWD;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)  // the accumulator starts at the bias
+        a1[u][i] = *reinterpret_cast<const f32x4 *>(smem + B1_OFF + (16 * i + 4 * c4) * 4);
+    }
+    // a tile whose whole halo patch lies inside the image (all but the frame's border tiles) needs no padding test
+    const bool interior = y0 >= 1 && y0 + TH + 1 <= H && x0 >= 1 && x0 + TW + 1 <= W;  // (block-uniform)
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      u32x4 bfr[NU];
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const char *rp = rawp + ((hyv[u] + 2 * m + (c4 >> 1)) * RAWP + hxv[u] + (c4 & 1) * 2) * 8;
+        const u32x2 lo = *reinterpret_cast<const u32x2 *>(rp), hi = *reinterpret_cast<const u32x2 *>(rp + 8);
+        bfr[u] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const u32x4 wfr = *reinterpret_cast<const u32x4 *>(smem + W1_OFF + ((i * 2 + m) * 64 + lane) * 16);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          if (wave + 8 * u < NGRP) {  // (wave-uniform)
+            if constexpr (P::ID == NQA_PREC_BF16)
+              a1[u][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wfr), __builtin_bit_cast(bf16x8, bfr[u]), a1[u][i], 0, 0, 0);
+            else
+              a1[u][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wfr), __builtin_bit_cast(f16x8, bfr[u]), a1[u][i], 0, 0, 0);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int q = qv[u];
+      const int gy = y0 - 1 + hyv[u], gx = x0 - 1 + hxv[u];
+      const bool inside = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      if (wave + 8 * u < NGRP && q < NQ) {
+        const int sw = lds_swz<true>(q);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {  // channels 16*i + 4*c4 .. +3: chunk i>>1, quarter 2*(i&1) + (c4>>1), half (c4&1)
+          t4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = P::from_f(fmaxf(a1[u][i][e], 0.f));
+          if (!interior && !inside) v = (t4){P::from_f(0.f), P::from_f(0.f), P::from_f(0.f), P::from_f(0.f)};
+          *reinterpret_cast<t4 *>(slot + (i >> 1) * CH_BYTES + q * 64 + (((2 * (i & 1) + (c4 >> 1)) ^ sw) << 4) +
+                                  (c4 & 1) * 8) = v;
+        }
+      }
+    }
+  };
+
+  const unsigned kOOB = 0x80000000u;
+  const unsigned img_out_bytes = (unsigned)H * (unsigned)W * (unsigned)COUT * (unsigned)sizeof(T);
+  // Pipeline per tile k: raw pixels fetched at tile k-2 (start) and committed to raw patch k&1 (end of k-2),
+  // conv1_1 -> halo image k&1 at tile k-1, conv1_2 at tile k.  ONE barrier per tile: behind it halo k (written
+  // during k-1) and raw patch k+1 (committed during k-1) are visible, and halo image (k+1)&1 / raw patch k&1,
+  // last read during tile k-1, are free.  The two waves of a SIMD (w, w+4) take conv1_1 and conv1_2 in opposite
+  // order, so the latency-bound conv1_1 of one runs beside the MFMA-bound conv1_2 of the other.
+  __syncthreads();  // zeroed patches, conv1_1 fragments and bias are in LDS
+  raw_fetch(0);
+  raw_commit(0);
+  raw_fetch(1);
+  raw_commit(1);
+  __syncthreads();
+  conv1_1_halo(0);
+  auto conv1_2_tile = [&](int it) {
+    int n, x0, y0;
+    tile_coords(it, n, x0, y0);
+    const char *slot = smem + (it & 1) * SLOT;
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+        out + (size_t)n * H * W * COUT, 0, img_out_bytes, 0x00020000);
+#pragma unroll 1
+    for (int pass = 0; pass < NPASS; ++pass) {
+      int q0[GPP];
+#pragma unroll
+      for (int g = 0; g < GPP; ++g) q0[g] = (ph * RW + pass) * HWD + g * 16 + l15;
+      asm volatile("" : "+v"(q0[0]), "+v"(q0[1]));
+      f32x4 acc[2][GPP];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < GPP; ++g) acc[i][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      // pixel fragments of k-step ks+1 are read while the MFMAs of ks run (two register sets; a third set, two steps
+      // of lead, measured 10 % SLOWER on conv2_1)
+      u32x4 bf[2][GPP];
+      auto load_b = [&](int ks, u32x4(&b)[GPP]) {
+        const int cc = ks / 9, t = ks - cc * 9, ky = t / 3, kx = t - ky * 3;
+#pragma unroll
+        for (int g = 0; g < GPP; ++g) {
+          const int q = q0[g] + ky * HWD + kx;
+          b[g] = *reinterpret_cast<const u32x4 *>(slot + cc * CH_BYTES + q * 64 + ((c4 ^ lds_swz<true>(q)) << 4));
+        }
+      };
+      load_b(0, bf[0]);
+#pragma unroll
+      for (int ks = 0; ks < 18; ++ks) {
+        if (ks + 1 < 18) load_b(ks + 1, bf[(ks + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < GPP; ++g)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            if constexpr (P::ID == NQA_PREC_BF16)
+              acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[i][ks]),
+                                                                  __builtin_bit_cast(bf16x8, bf[ks & 1][g]), acc[i][g], 0, 0, 0);
+            else
+              acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wf[i][ks]),
+                                                                 __builtin_bit_cast(f16x8, bf[ks & 1][g]), acc[i][g], 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int g = 0; g < GPP; ++g) {
+        const int gy = y0 + ph * RW + pass, gx = x0 + g * 16 + l15;
+        const bool inside = gy < H && gx < W;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          t4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = P::from_f(fmaxf(acc[i][g][e] + bia[i][e], 0.f));
+          const unsigned off =
+              inside ? (unsigned)(((gy * W + gx) * COUT + cg * 32 + i * 16 + 4 * c4) * (int)sizeof(T)) : kOOB;
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), orsrc, off, 0, 0);
+        }
+      }
+    }
+  };
+  for (int it = 0; it < my_tiles; ++it) {
+    __syncthreads();
+    raw_fetch(it + 2);  // lands under this tile's MFMAs
+    const bool next = it + 1 < my_tiles;
+#if defined(NQA_R_NO_P1)  // timing-only ablations (tools/gpu_fused_bench.py; results are wrong on purpose)
+    conv1_2_tile(it);
+    (void)next;
+#elif defined(NQA_R_NO_P2)
+    if (next) conv1_1_halo(it + 1);
+#else
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {  // (a loop, so that each phase's code exists once)
+      if ((half == 0) == (wave < 4))
+        conv1_2_tile(it);
+      else if (next)
+        conv1_1_halo(it + 1);
+    }
+#endif
+    raw_commit(it & 1);  // tile it+2's patch; patch it&1 was last read by conv1_1 of tile `it`, during tile it-1
   }
 #endif
 }
@@ -1560,6 +1828,36 @@ static int launch_conv1_tile(const float *x, const float *y, int B, int n, int H
   return check_launch("conv1_tile");
 }
 
+template <typename P>
+static int launch_conv1_regw(const float *x, const float *y, int B, int n, int H, int W, const char *packed, void *out,
+                             hipStream_t st) {
+  constexpr int LDS = 2 * 2 * 1536 * 16 + 2 * 13 * 40 * 8 + 4 * 2 * 64 * 16 + 256;
+  static bool attr_done_dev[64] = {false};
+  bool &attr_done = attr_done_dev[current_device() & 63];
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv1_regw_kernel<P>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+      set_error("conv1_regw: cannot raise the dynamic LDS limit to %d bytes", LDS);
+      return NQA_E_LAUNCH;
+    }
+    attr_done = true;
+  }
+  const int cus = num_cus();
+  if (!cus) {
+    set_error("conv1_regw: cannot query the device");
+    return NQA_E_LAUNCH;
+  }
+  const int tiles_x = cdiv(W, 32), tiles_y = cdiv(H, 8), total = n * tiles_x * tiles_y;
+  const int grid = total < cus ? total : cus;
+  const float *b1 = reinterpret_cast<const float *>(packed + layer_bias_offset(0, P::ID));
+  const float *b2 = reinterpret_cast<const float *>(packed + layer_bias_offset(1, P::ID));
+  TimedLaunch t(NQA_K_CONV, st);
+  conv1_regw_kernel<P><<<grid, 512, LDS, st>>>(x, y, B, packed + layer0_m16_offset(P::ID), b1,
+                                               packed + regw_offset(1, P::ID), b2,
+                                               reinterpret_cast<typename P::T *>(out), H, W, tiles_x, tiles_y, total);
+  return check_launch("conv1_regw");
+}
+
 // stage 1 (conv1_1 + conv1_2) of images [x(0..B), y(0..n-B)) in one kernel; 16-bit modes only
 int conv1_fused(const float *x, const float *y, int B, int n, int H, int W, const void *packed, int prec, void *out,
                 hipStream_t st) {
@@ -1568,6 +1866,12 @@ int conv1_fused(const float *x, const float *y, int B, int n, int H, int W, cons
     switch (prec) {
       case NQA_PREC_BF16: return launch_conv1_tile<PrecBF16>(x, y, B, n, H, W, p, out, st);
       case NQA_PREC_F16: return launch_conv1_tile<PrecF16>(x, y, B, n, H, W, p, out, st);
+    }
+  }
+  if (g_stage1_variant == 0 && !(g_ring3 & 1)) {  // the shipped form (ring bit 0 selects the first form for A/B runs)
+    switch (prec) {
+      case NQA_PREC_BF16: return launch_conv1_regw<PrecBF16>(x, y, B, n, H, W, p, out, st);
+      case NQA_PREC_F16: return launch_conv1_regw<PrecF16>(x, y, B, n, H, W, p, out, st);
     }
   }
   switch (prec) {
