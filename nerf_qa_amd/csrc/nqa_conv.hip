@@ -815,7 +815,11 @@ __global__ __launch_bounds__(512) void conv1_regw_kernel(const float *__restrict
   typedef typename P::T T;
   typedef __attribute__((ext_vector_type(4))) T t4;
   constexpr int NCG = 2, COUT = 64, TH = 8, TW = 32, HWD = TW + 2, NQ = (TH + 2) * HWD;  // 340 halo pixels
-  constexpr int CH_BYTES = 1536 * 16, SLOT = 2 * CH_BYTES;
+  // halo image [chunk][pixel][96 B]: a pixel's 32 channels (64 B) + 32 B of padding.  With a 96-byte pitch a
+  // ds_read_b128 of 16 consecutive pixels at one 16-byte quarter is bank-conflict-free WITHOUT an XOR swizzle (the
+  // image is written by ds_write here, not by 1-KB LDS-DMA pieces, so the pitch is free), and then a tap is a
+  // compile-time byte offset from one per-group base register: no address arithmetic in the k loop.
+  constexpr int PITCH = 96, CH_BYTES = 352 * PITCH, SLOT = 2 * CH_BYTES;
   constexpr int RAWP = 40, RAW_ROWS = 13, RAW_BYTES = RAW_ROWS * RAWP * 8;  // (+1 row read, with zero weights, by MFMA 1)
   constexpr int RAW_OFF = 2 * SLOT, W1_OFF = RAW_OFF + 2 * RAW_BYTES, B1_OFF = W1_OFF + 4 * 2 * 64 * 16;  // two raw patches
   constexpr int RW = NCG, GPP = 2, NPASS = 2 * RW / GPP;
@@ -940,14 +944,13 @@ __global__ __launch_bounds__(512) void conv1_regw_kernel(const float *__restrict
       const int gy = y0 - 1 + hyv[u], gx = x0 - 1 + hxv[u];
       const bool inside = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
       if (wave + 8 * u < NGRP && q < NQ) {
-        const int sw = lds_swz<true>(q);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {  // channels 16*i + 4*c4 .. +3: chunk i>>1, quarter 2*(i&1) + (c4>>1), half (c4&1)
           t4 v;
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = P::from_f(fmaxf(a1[u][i][e], 0.f));
           if (!interior && !inside) v = (t4){P::from_f(0.f), P::from_f(0.f), P::from_f(0.f), P::from_f(0.f)};
-          *reinterpret_cast<t4 *>(slot + (i >> 1) * CH_BYTES + q * 64 + (((2 * (i & 1) + (c4 >> 1)) ^ sw) << 4) +
+          *reinterpret_cast<t4 *>(slot + (i >> 1) * CH_BYTES + q * PITCH + ((2 * (i & 1) + (c4 >> 1)) << 4) +
                                   (c4 & 1) * 8) = v;
         }
       }
@@ -976,9 +979,9 @@ __global__ __launch_bounds__(512) void conv1_regw_kernel(const float *__restrict
         out + (size_t)n * H * W * COUT, 0, img_out_bytes, 0x00020000);
 #pragma unroll 1
     for (int pass = 0; pass < NPASS; ++pass) {
-      int q0[GPP];
+      int q0[GPP];  // byte offset of this lane's fragment at tap (0,0), chunk 0, per 16-pixel group
 #pragma unroll
-      for (int g = 0; g < GPP; ++g) q0[g] = (ph * RW + pass) * HWD + g * 16 + l15;
+      for (int g = 0; g < GPP; ++g) q0[g] = ((ph * RW + pass) * HWD + g * 16 + l15) * PITCH + (c4 << 4);
       asm volatile("" : "+v"(q0[0]), "+v"(q0[1]));
       f32x4 acc[2][GPP];
 #pragma unroll
@@ -991,10 +994,8 @@ __global__ __launch_bounds__(512) void conv1_regw_kernel(const float *__restrict
       auto load_b = [&](int ks, u32x4(&b)[GPP]) {
         const int cc = ks / 9, t = ks - cc * 9, ky = t / 3, kx = t - ky * 3;
 #pragma unroll
-        for (int g = 0; g < GPP; ++g) {
-          const int q = q0[g] + ky * HWD + kx;
-          b[g] = *reinterpret_cast<const u32x4 *>(slot + cc * CH_BYTES + q * 64 + ((c4 ^ lds_swz<true>(q)) << 4));
-        }
+        for (int g = 0; g < GPP; ++g)
+          b[g] = *reinterpret_cast<const u32x4 *>(slot + q0[g] + (cc * CH_BYTES + (ky * HWD + kx) * PITCH));
       };
       load_b(0, bf[0]);
 #pragma unroll
@@ -1831,7 +1832,7 @@ static int launch_conv1_tile(const float *x, const float *y, int B, int n, int H
 template <typename P>
 static int launch_conv1_regw(const float *x, const float *y, int B, int n, int H, int W, const char *packed, void *out,
                              hipStream_t st) {
-  constexpr int LDS = 2 * 2 * 1536 * 16 + 2 * 13 * 40 * 8 + 4 * 2 * 64 * 16 + 256;
+  constexpr int LDS = 2 * 2 * 352 * 96 + 2 * 13 * 40 * 8 + 4 * 2 * 64 * 16 + 256;
   static bool attr_done_dev[64] = {false};
   bool &attr_done = attr_done_dev[current_device() & 63];
   if (!attr_done) {
