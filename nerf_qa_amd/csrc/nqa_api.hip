@@ -269,13 +269,13 @@ int nqa_version(void) { return NQA_VERSION; }
 const char *nqa_last_error(void) { return g_err; }
 
 int nqa_set_conv_variant(int variant) {
-  if (variant < 0 || variant > 63 || (variant & 3) == 3) {
+  if (variant < 0 || variant > 31 || (variant & 3) == 3) {
     set_error("set_conv_variant: unknown variant %d", variant);
     return NQA_E_ARG;
   }
   set_conv_variant(variant & 7);
   set_adists_window_legacy((variant & 8) != 0);
-  set_conv_ring((variant >> 4) & 3);
+  set_conv_first_forms((variant >> 4) & 1);
   return NQA_OK;
 }
 

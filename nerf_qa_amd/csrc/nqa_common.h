@@ -164,7 +164,7 @@ size_t max_act_elems(int H, int W);  // largest activation map of the pyramid, e
 
 // ---- host launchers shared between translation units ---------------------------------
 void set_conv_variant(int v);
-void set_conv_ring(int r);
+void set_conv_first_forms(int on);
 void set_adists_window_legacy(bool on);
 int conv1_1(const float *x, int n, int H, int W, const void *packed, int prec, void *out, hipStream_t st);
 int conv1_fused(const float *x, const float *y, int B, int n, int H, int W, const void *packed, int prec, void *out,

@@ -166,10 +166,6 @@ struct ConvGeom {
   static constexpr int W_BYTES = W_ITEMS * 16;
   static constexpr int W_ROUNDS = W_ITEMS / THREADS;
   static constexpr int LDS_BYTES = 2 * (A_BYTES + W_BYTES);
-  // three-deep weight ring (NWB = 3): halo buffers padded to whole DMA rounds, so that every wave issues the
-  // same number of pieces per stage and the loop can retire them with counted vmcnt waits
-  static constexpr int A_FULL_BYTES = A_ROUNDS * THREADS * 16;
-  static constexpr int LDS_BYTES3 = 2 * A_FULL_BYTES + 3 * W_BYTES;
   static_assert(BN % 64 == 0 && W_ITEMS % THREADS == 0 && MP % TW == 0, "bad conv geometry");
 };
 
@@ -184,21 +180,14 @@ __host__ __device__ inline int lds_swz(int r) {
 
 // M16: 16-bit modes on v_mfma_f32_16x16x32 (the chip holds a higher clock on it than on 32x32x16
 // at equal cycles per FLOP); weights of those layers are packed with the matching swizzle.
-// NWB = 2: two weight buffers, stage s+1 requested when stage s has landed (one stage of cover: enough when a
-// stage's MFMAs outlast the ~1.1 us an LDS-DMA takes under load -- the 8-wave 256 x 256 tile).  NWB = 3: three
-// weight buffers, stage s+2 requested at stage s and the next chunk's halo three stages ahead, retired with
-// COUNTED vmcnt waits, for the tiles whose stage is shorter than that latency (128-channel layers, narrow maps).
-template <typename P, int WAVES_N, int WAVES_M, int WN_T, int WM_T, int TW, bool M16, int NWB = 2>
+template <typename P, int WAVES_N, int WAVES_M, int WN_T, int WM_T, int TW, bool M16>
 __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void conv3x3_igemm_kernel(
     const typename P::T *__restrict__ in, const char *__restrict__ wpk, const float *__restrict__ bias,
     typename P::T *__restrict__ out, int H, int W, int Cin, int Cout, int tiles_x, int out_split) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the LDS-DMA builtin exists in the device pass only
   typedef typename P::T T;
   typedef ConvGeom<WAVES_N, WAVES_M, WN_T, WM_T, TW> G;
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [A0][A1][W0][W1]([W2])
-  constexpr int AB = NWB == 3 ? G::A_FULL_BYTES : G::A_BYTES;  // halo buffer stride
-  constexpr int WOFF = 2 * AB;                                  // first weight buffer
-  constexpr int A_LIMIT = NWB == 3 ? G::A_ROUNDS * G::THREADS : G::A_ITEMS_PAD;  // DMA items per halo buffer
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [A0][A1][W0][W1]
 
   const int tid = threadIdx.x, lane = tid & 63;
   // the wave index as a provably wave-uniform (SGPR) value: every LDS-DMA destination is then
@@ -233,10 +222,10 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void conv3x3_igemm_kernel(
     const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
     const bool ok = i < G::A_ITEMS && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
     a_goff[r] = ok ? (unsigned)(((gy * W + gx) * Cin + c * P::CPC) * (int)sizeof(T)) : kOOB;
-    if (!ok && i < A_LIMIT) {
+    if (!ok && i < G::A_ITEMS_PAD) {
       const u32x4 z = {0u, 0u, 0u, 0u};
       *reinterpret_cast<u32x4 *>(smem + i * 16) = z;
-      *reinterpret_cast<u32x4 *>(smem + AB + i * 16) = z;
+      *reinterpret_cast<u32x4 *>(smem + G::A_BYTES + i * 16) = z;
     }
   }
   const unsigned img_bytes = (unsigned)H * (unsigned)W * (unsigned)Cin * (unsigned)sizeof(T);
@@ -257,30 +246,24 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void conv3x3_igemm_kernel(
   // hipcc does not count buffer-to-LDS DMA in its s_waitcnt bookkeeping (and with
   // global_load_lds it degrades every LDS wait in the loop to lgkmcnt(0)), so the DMA is
   // retired by hand: dma_wait() before the barrier that publishes a stage.
-  auto issue_w = [&](int s, int buf) {
+  auto issue = [&](int s) {
 #ifndef NQA_ABLATE_NO_DMA
-    char *wdst = smem + WOFF + buf * G::W_BYTES + wave_base;
+    const int cc = s / 3;
+    char *wdst = smem + 2 * G::A_BYTES + (s & 1) * G::W_BYTES + wave_base;
 #pragma unroll
     for (int r = 0; r < G::W_ROUNDS; ++r)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void_t *)(wdst + r * G::THREADS * 16), 16, w_goff[r],
                                                s * (G::SUB_STAGE_ITEMS * 16), 0, 0);
-#endif
-  };
-  auto issue_a = [&](int cc) {
-#ifndef NQA_ABLATE_NO_DMA
-    char *adst = smem + (cc & 1) * AB + wave_base;
+    if (s - cc * 3 == 0) {
+      char *adst = smem + (cc & 1) * G::A_BYTES + wave_base;
 #pragma unroll
-    for (int r = 0; r < G::A_ROUNDS; ++r) {
-      if (NWB == 3 || r * G::THREADS + wave * 64 < G::A_ITEMS_PAD)  // wave-uniform
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_void_t *)(adst + r * G::THREADS * 16), 16, a_goff[r],
-                                                 cc * 64, 0, 0);
+      for (int r = 0; r < G::A_ROUNDS; ++r) {
+        if (r * G::THREADS + wave * 64 < G::A_ITEMS_PAD)  // wave-uniform
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_void_t *)(adst + r * G::THREADS * 16), 16, a_goff[r],
+                                                   cc * 64, 0, 0);
+      }
     }
 #endif
-  };
-  auto issue = [&](int s) {
-    const int cc = s / 3;
-    issue_w(s, s & 1);
-    if (s - cc * 3 == 0) issue_a(cc);
   };
   auto dma_wait = [] { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
 
@@ -290,7 +273,7 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void conv3x3_igemm_kernel(
   for (int i = 0; i < WN_T; ++i) {
     const int cib = (wn * WN_T + i) * 32 + l31;
     const int r64 = cib & 63;
-    w_base[i] = WOFF + (cib >> 6) * (G::SUB_STAGE_ITEMS * 16) + r64 * 64;
+    w_base[i] = 2 * G::A_BYTES + (cib >> 6) * (G::SUB_STAGE_ITEMS * 16) + r64 * 64;
     w_sw[i] = (r64 >> 2) & 3;
   }
   int q0[WM_T];  // halo index of this lane's output pixel at tap (0,0)
@@ -318,7 +301,7 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void conv3x3_igemm_kernel(
     for (int i = 0; i < 2 * WN_T; ++i) {
       const int cib = wn * WN_T * 32 + i * 16 + l15;
       const int r64 = cib & 63;
-      w16_addr[i] = WOFF + (cib >> 6) * (G::SUB_STAGE_ITEMS * 16) + r64 * 64 + ((c4 ^ lds_swz<true>(r64)) << 4);
+      w16_addr[i] = 2 * G::A_BYTES + (cib >> 6) * (G::SUB_STAGE_ITEMS * 16) + r64 * 64 + ((c4 ^ lds_swz<true>(r64)) << 4);
     }
 #pragma unroll
     for (int j = 0; j < 2 * WM_T; ++j) {
@@ -335,8 +318,21 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void conv3x3_igemm_kernel(
 #ifdef NQA_STAMPS
   unsigned long long seg_sum[4] = {0, 0, 0, 0};
 #endif
-  // one stage's MFMA work: kernel row ky of the chunk whose halo is at abuf, weights at wbuf (+ WOFF inside w_base)
-  auto compute_stage = [&](const char *abuf, const char *wbuf, int ky) {
+  issue(0);
+  for (int s = 0; s < S; ++s) {
+    const int cc = s / 3, ky = s - cc * 3;
+    NQA_STAMP(t0);
+    dma_wait();       // this wave's DMA for stage s has landed
+    NQA_STAMP(t1);
+    __syncthreads();  // ... and everyone's; every wave has also finished reading stage s-1
+    NQA_STAMP(t2);
+    if (s + 1 < S) issue(s + 1);
+    NQA_STAMP(t3);
+    NQA_STAMP_ADD(0, t0, t1);
+    NQA_STAMP_ADD(1, t1, t2);
+    NQA_STAMP_ADD(2, t2, t3);
+    const char *abuf = smem + (cc & 1) * G::A_BYTES;
+    const char *wbuf = smem + (s & 1) * G::W_BYTES;
     // six k-steps per stage (3 taps x 2 chunk pairs); fragments of step t+1 are read from LDS
     // while the MFMAs of step t run (two register sets, static indices)
     auto load_frags = [&](int t, u32x4(&af)[WN_T], u32x4(&bf)[WM_T]) {
@@ -464,55 +460,8 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void conv3x3_igemm_kernel(
       __builtin_amdgcn_sched_barrier(0);
     }
     }
-  };
-  if constexpr (NWB == 2) {
-    issue(0);
-    for (int s = 0; s < S; ++s) {
-      const int cc = s / 3, ky = s - cc * 3;
-      NQA_STAMP(t0);
-      dma_wait();       // this wave's DMA for stage s has landed
-      NQA_STAMP(t1);
-      __syncthreads();  // ... and everyone's; every wave has also finished reading stage s-1
-      NQA_STAMP(t2);
-      if (s + 1 < S) issue(s + 1);
-      NQA_STAMP(t3);
-      NQA_STAMP_ADD(0, t0, t1);
-      NQA_STAMP_ADD(1, t1, t2);
-      NQA_STAMP_ADD(2, t2, t3);
-      compute_stage(smem + (cc & 1) * AB, smem + (s & 1) * G::W_BYTES, ky);
-      NQA_STAMP(t4);
-      NQA_STAMP_ADD(3, t3, t4);
-    }
-  } else {
-    // Three weight buffers (stage s lives in buffer s % 3 = ky).  Issue order per wave: A(0), W(0), W(1), then at
-    // stage s (behind its barrier) W(s+2) and, on a chunk's first row, A(cc+1).  vmcnt retires in issue order,
-    // so "stage s has landed" = everything up to W(s) is done = at most the YOUNGER pieces are outstanding:
-    // W(s+1) always, plus A(cc+1) when it was issued after W(s) (rows 1 and 2 of a chunk that has a successor).
-    // The halo A(cc) was issued three stages back, before W(3cc): waiting for W(3cc) covers it.
-    constexpr int NWP = G::W_ROUNDS, NAP = G::A_ROUNDS;
-    issue_a(0);
-    issue_w(0, 0);
-    if (S > 1) issue_w(1, 1);
-    for (int cc = 0; cc < nCC; ++cc) {
-      const bool next_chunk = cc + 1 < nCC;  // (block-uniform)
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-        const int s = cc * 3 + ky;
-        if (s + 1 >= S)
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (ky == 0 || !next_chunk)
-          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWP) : "memory");
-        else
-          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWP + NAP) : "memory");
-        // raw barrier: __syncthreads() would add vmcnt(0) and drain the pieces meant to stay in flight.
-        // Every wave's LDS reads of stage s-1 have returned (their MFMAs consumed them), so the buffers the
-        // new DMAs overwrite are free once all waves are here.
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (s + 2 < S) issue_w(s + 2, (ky + 2) % 3);
-        if (ky == 0 && next_chunk) issue_a(cc + 1);
-        compute_stage(smem + (cc & 1) * AB, smem + ky * G::W_BYTES, ky);
-      }
-    }
+    NQA_STAMP(t4);
+    NQA_STAMP_ADD(3, t3, t4);
   }
 #ifdef NQA_STAMPS
   if (lane == 0) {
@@ -531,7 +480,7 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void conv3x3_igemm_kernel(
   // consecutive chunks of one record: full-line writes.
   constexpr int RB = G::BN * (int)sizeof(T), NCH = RB / 16, SWZ = NCH >= 16 ? 15 : NCH - 1;
   constexpr int ROWS = WAVES_M * 32;
-  static_assert(ROWS * RB <= (NWB == 3 ? G::LDS_BYTES3 : G::LDS_BYTES), "epilogue tile does not fit the stage buffers");
+  static_assert(ROWS * RB <= G::LDS_BYTES, "epilogue tile does not fit the stage buffers");
   char *const obase = reinterpret_cast<char *>(out) + (size_t)ct * RB;
   const size_t rec = (size_t)Cout * sizeof(T);
   // one lane's piece: 4 consecutive channels (first = cl, block-local) of the pixel staged in `row`
@@ -1631,12 +1580,12 @@ static int current_device() {
 // another thread's calls launch
 static thread_local int g_conv_variant = 1;  // 0: 4-wave tiles everywhere; 1: + 8-wave 256x256 tiles; 2: + 8-wave 128x512 tiles
 static thread_local int g_stage1_variant = 0;  // 0: persistent two-phase kernel (conv1_fused_kernel); 1: conv1_tile_kernel
-static thread_local int g_ring3 = 0;  // experiments: bit 0 = three-deep weight ring on the 4-wave tiles, bit 1 = 8-wave 128 x 256 ring tiles on 128-channel layers
+static thread_local int g_first_forms = 0;  // 1: the round-1 forms of stage 1 (two-phase kernel) and conv2_1 (implicit GEMM), for A/B timing
 void set_conv_variant(int v) {
   g_conv_variant = v & 3;
   g_stage1_variant = (v >> 2) & 1;
 }
-void set_conv_ring(int r) { g_ring3 = r; }
+void set_conv_first_forms(int on) { g_first_forms = on; }
 
 template <typename P>
 static int launch_conv1_1(const float *x, int n, int H, int W, const char *packed, void *out, hipStream_t st) {
@@ -1648,18 +1597,16 @@ static int launch_conv1_1(const float *x, int n, int H, int W, const char *packe
   return check_launch("conv1_1");
 }
 
-template <typename P, int WAVES_N, int WAVES_M, int WN_T, int WM_T, int TW, bool M16 = (sizeof(typename P::T) == 2),
-          int NWB = 2>
+template <typename P, int WAVES_N, int WAVES_M, int WN_T, int WM_T, int TW, bool M16 = (sizeof(typename P::T) == 2)>
 static int launch_igemm(const void *in, int n, int H, int W, int cin, int cout, const char *wpk, const float *bias,
                         void *out, int out_split, hipStream_t st) {
   typedef ConvGeom<WAVES_N, WAVES_M, WN_T, WM_T, TW> G;
-  constexpr int LDS = NWB == 3 ? G::LDS_BYTES3 : G::LDS_BYTES;
   static bool attr_done_dev[64] = {false};  // the attribute is per device: a process may drive several
   bool &attr_done = attr_done_dev[current_device() & 63];
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_igemm_kernel<P, WAVES_N, WAVES_M, WN_T, WM_T, TW, M16, NWB>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
-      set_error("conv3x3_igemm: cannot raise the dynamic LDS limit to %d bytes", LDS);
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_igemm_kernel<P, WAVES_N, WAVES_M, WN_T, WM_T, TW, M16>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES) != hipSuccess) {
+      set_error("conv3x3_igemm: cannot raise the dynamic LDS limit to %d bytes", G::LDS_BYTES);
       return NQA_E_LAUNCH;
     }
     attr_done = true;
@@ -1667,7 +1614,7 @@ static int launch_igemm(const void *in, int n, int H, int W, int cin, int cout, 
   const int tiles_x = cdiv(W, TW), tiles_y = cdiv(H, G::TH);
   dim3 grid(tiles_x * tiles_y, n, cout / G::BN);
   TimedLaunch t(NQA_K_CONV, st);
-  conv3x3_igemm_kernel<P, WAVES_N, WAVES_M, WN_T, WM_T, TW, M16, NWB><<<grid, G::THREADS, LDS, st>>>(
+  conv3x3_igemm_kernel<P, WAVES_N, WAVES_M, WN_T, WM_T, TW, M16><<<grid, G::THREADS, G::LDS_BYTES, st>>>(
       reinterpret_cast<const typename P::T *>(in), wpk, bias, reinterpret_cast<typename P::T *>(out), H, W, cin, cout,
       tiles_x, out_split);
   return check_launch("conv3x3_igemm");
@@ -1713,14 +1660,14 @@ static int launch_conv(const void *in, int n, int H, int W, int layer, const cha
   const bool narrow = W <= 16;  // 32-wide tiles would be half empty
   const int out_split = P::SPLIT && !cs.last;  // f32s: tapped layers leave as float, the others as split16
   // 8-wave 256 ch x 256 px tiles run ~10 % faster per FLOP than 4-wave 128 x 128 tiles on layers
-  // with >= 256 output channels (measured), unless their coarser pixel tiling wastes more than half
+  // with >= 256 output channels (measured), unless their coarser pixel tiling wastes more than most
   // of that on the map's ragged edge (e.g. 68x120) or the map is narrow.  (An 8-wave 128 ch x 256 px
   // tile for the 128-channel layers measured 5-9 % SLOWER than the 4-wave tile.)
   bool big = g_conv_variant >= 1 && cs.cout >= 256 && !narrow;
   if (big) {
     const double eff_big = (double)H * W / ((double)cdiv(W, 32) * cdiv(H, 8) * 256.0);
     const double eff_small = (double)H * W / ((double)cdiv(W, 32) * cdiv(H, 4) * 128.0);
-    big = eff_big * 1.05 >= eff_small;
+    big = eff_big * 1.05 >= eff_small;  // (1.10 tried: the 68 x 120 maps of a 1080p frame then lose 10 % to the 8-wave grid's tail)
     // small batches: a grid of 8-wave tiles that cannot give every CU a block leaves most of the chip
     // idle for the whole layer; four times as many 4-wave tiles fill it better
     const long blocks_big = (long)cdiv(W, 32) * cdiv(H, 8) * n * (cs.cout / 256);
@@ -1746,13 +1693,8 @@ static int launch_conv(const void *in, int n, int H, int W, int layer, const cha
     if (wide) return launch_igemm<P, 2, 4, 2, 4, 32>(in, n, H, W, cs.cin, cs.cout, wpk, bias, out, out_split, st);
   }
   if constexpr (sizeof(typename P::T) == 2) {
-    if (layer == 2 && !(g_ring3 & 1) && W >= 16) return launch_regw<P>(in, n, H, W, layer, packed, out, st);
-    if ((g_ring3 & 2) && cs.cout == 128 && !narrow)  // 128 ch x 256 px, 8 waves, three-deep weight ring
-      return launch_igemm<P, 2, 4, 2, 2, 32, true, 3>(in, n, H, W, cs.cin, cs.cout, wpk, bias, out, out_split, st);
-    if ((g_ring3 & 1) && !big) {  // 128 ch x 128 px, 4 waves, three-deep weight ring
-      return narrow ? launch_igemm<P, 2, 2, 2, 2, 16, true, 3>(in, n, H, W, cs.cin, cs.cout, wpk, bias, out, out_split, st)
-                    : launch_igemm<P, 2, 2, 2, 2, 32, true, 3>(in, n, H, W, cs.cin, cs.cout, wpk, bias, out, out_split, st);
-    }
+    // conv2_1: register-resident weights (first-form bit of nqa_set_conv_variant: the implicit GEMM, for A/B runs)
+    if (layer == 2 && !g_first_forms && W >= 16) return launch_regw<P>(in, n, H, W, layer, packed, out, st);
   }
   if (!big) { NQA_GO(2, 2, 2, 2); }                             // 128 ch x 128 px, 4 waves
   NQA_GO(2, 4, 4, 2);                                           // 256 ch x 256 px, 8 waves
@@ -1869,7 +1811,7 @@ int conv1_fused(const float *x, const float *y, int B, int n, int H, int W, cons
       case NQA_PREC_F16: return launch_conv1_tile<PrecF16>(x, y, B, n, H, W, p, out, st);
     }
   }
-  if (g_stage1_variant == 0 && !(g_ring3 & 1)) {  // the shipped form (ring bit 0 selects the first form for A/B runs)
+  if (g_stage1_variant == 0 && !g_first_forms) {  // the shipped form
     switch (prec) {
       case NQA_PREC_BF16: return launch_conv1_regw<PrecBF16>(x, y, B, n, H, W, p, out, st);
       case NQA_PREC_F16: return launch_conv1_regw<PrecF16>(x, y, B, n, H, W, p, out, st);
