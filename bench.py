@@ -299,13 +299,13 @@ def main():
     wl = WORKLOADS[args.workload]
 
     def rank_times(dt):
-        """(max over ranks, per-rank list) of a rank's wall time."""
+        """(max over ranks, per-rank list) of a rank's wall time (one all_gather_into_tensor, as for the scores)."""
         if world == 1:
             return dt, [dt]
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        allt = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(allt, t)
-        per = [float(v.item()) for v in allt]
+        t = torch.tensor([dt], dtype=torch.float32, device=dev)
+        allt = torch.empty(world, dtype=torch.float32, device=dev)
+        dist.all_gather_into_tensor(allt, t)
+        per = [float(v) for v in allt.cpu().tolist()]
         return max(per), per
 
     if args.workload == "video10k":
