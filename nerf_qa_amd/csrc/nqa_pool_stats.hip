@@ -168,9 +168,14 @@ __global__ __launch_bounds__(256) void pool_stats_kernel(const typename P::T *__
     unpack2<P>(vx, m.px);
     unpack2<P>(vy, m.py);
   }
+  tvec keepx[3], keepy[3];  // bottom row of the previous window of this thread
+  bool have_prev = false;
   for (int t = pl; t < tile_units; t += PL) {
     const int oy = oy0 + t / TC, ox = ox0 + t % TC;
-    if (oy >= Ho || ox >= Wo) continue;
+    if (oy >= Ho || ox >= Wo) {
+      have_prev = false;
+      continue;
+    }
     const int u = oy * Wo + ox;
     // All 18 loads go out unconditionally, back to back (a branch per tap would serialise them into
     // 9 round trips).  A window that lies wholly inside the image -- almost all of them -- takes the
@@ -182,11 +187,19 @@ __global__ __launch_bounds__(256) void pool_stats_kernel(const typename P::T *__
     tvec vx[9], vy[9];
     if (interior) {
       const size_t o0 = ((size_t)iy0 * W + ix0) * C;
+      // the window's top row is the previous window's bottom row when this thread's previous pooled pixel was the
+      // one directly above (tiles are one pass wide, so that is the previous iteration) and was interior too
+      const bool reuse = TC == PL && have_prev;
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const size_t o = o0 + ((size_t)(t / 3) * W + (t % 3)) * C;
-        vx[t] = *reinterpret_cast<const tvec *>(fx + o);
-        vy[t] = *reinterpret_cast<const tvec *>(fy + o);
+        if (t < 3 && reuse) {
+          vx[t] = keepx[t];
+          vy[t] = keepy[t];
+        } else {
+          vx[t] = *reinterpret_cast<const tvec *>(fx + o);
+          vy[t] = *reinterpret_cast<const tvec *>(fy + o);
+        }
       }
     } else {
 #pragma unroll
@@ -235,6 +248,12 @@ __global__ __launch_bounds__(256) void pool_stats_kernel(const typename P::T *__
         }
       }
     }
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      keepx[t] = vx[6 + t];
+      keepy[t] = vy[6 + t];
+    }
+    have_prev = interior;
     float px[P::CPC], py[P::CPC];
 #pragma unroll
     for (int e = 0; e < P::CPC; ++e) {
@@ -477,10 +496,9 @@ int pool_stats_tiles(int Ho, int Wo, int C, int prec, int B, int *tr, int *tc) {
   const int upb = stats_units_per_block(Ho * Wo, C, prec, B);
   const int esz = (int)prec_elem_bytes(prec), cpc = 16 / esz;
   const int PL = 256 / (C / cpc);  // pooled pixels per pass of the block
-  int TC = 8192 / (C * esz);
-  TC = TC > 32 ? 32 : TC;
-  TC = TC < PL ? PL : TC / PL * PL;
-  if (TC > Wo) TC = cdiv(Wo, PL) * PL;
+  // exactly one pass wide: a thread then walks ONE column of the tile from top to bottom and can keep the input
+  // row that two vertically adjacent 3x3 windows share in registers (6 + 6 loads per pooled pixel instead of 9 + 9)
+  int TC = PL;
   int TR = upb / TC;
   if (TR < 1) TR = 1;
   if (TR > Ho) TR = Ho;
