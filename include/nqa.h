@@ -193,7 +193,8 @@ int nqa_resize_pil_bilinear_u8(const uint8_t *in, int n, int Hin, int Win, int H
  * layer, 1 (default) = + 8-wave 256 ch x 256 px tiles on layers with >= 256 output channels, 2 =
  * + 8-wave 128 ch x 512 px tiles wherever the map is large enough (measured equal to 1).
  * Adding 4 selects the tile form of the fused stage-1 kernel; adding 16 selects the round-1 forms of stage 1 (the
- * persistent two-phase kernel) and of conv2_1 (the implicit GEMM) instead of the register-resident-weights kernels;
+ * persistent two-phase kernel) and of conv2_1 (the implicit GEMM) instead of the register-resident-weights kernels,
+ * adding 32 the implicit GEMM for conv2_2 / conv3_1;
  * adding 8 selects the first form of the A-DISTS window pass (every wave loads its own taps instead of sharing them
  * through LDS).  Results agree in every variant to the rounding of a different summation order inside a layer (the
  * tile variants are bit-identical); this only exists so they can be timed against each other in one process.

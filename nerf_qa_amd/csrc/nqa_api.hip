@@ -70,21 +70,22 @@ size_t layer_offset(int layer, int prec) {
   return o;
 }
 size_t layer0_mfma_offset(int prec) { return layer_offset(0, prec) + align_up(27 * 64 * 4 + 64 * 4, 256); }
-// Register-resident weight fragments of the 64-input-channel layers (conv1_2 = layer 1, conv2_1 = layer 2), 16-bit
-// modes only: the whole layer as 16x16x32 MFMA A fragments [cout/32][2 tiles of 16][18 k-steps][64 lanes][8 halfs],
+// Register-resident weight fragments of layers 1..4 (conv1_2, conv2_1: Cin 64; conv2_2, conv3_1: Cin 128), 16-bit
+// modes only: the whole layer as 16x16x32 MFMA A fragments [cout/32][2 tiles of 16][Cin/32*9 k-steps][64 lanes][8 halfs],
 // k-step = chunk * 9 + tap (chunk = 32 input channels), lane = (row l15, k-group c4): element j is
 // w[cout = 32*g + 16*i + l15][cin = 32*chunk + 8*c4 + j][tap].  conv3x3_regw_kernel loads its 2 x 18 fragments
 // (144 VGPRs) once per persistent block.  Appended behind the ordinary layers.
-size_t regw_bytes(int layer) { return (size_t)kConvs[layer].cout * 64 * 9 * 2; }
+size_t regw_bytes(int layer) { return (size_t)kConvs[layer].cout * kConvs[layer].cin * 9 * 2; }
+static const int kRegwFirst = 1, kRegwLast = 4;  // conv1_2, conv2_1 (Cin 64); conv2_2, conv3_1 (Cin 128)
 // conv1_1 as 16x16x32 MFMA A fragments for conv1_regw_kernel: [4 tiles of 16 channels][2 MFMAs][64 lanes][8 halfs];
 // MFMA m contracts kernel rows 2m and 2m+1: k = 16*(ky - 2m) + 4*kx + c (kx, c padded to 4; zero for ky = 3)
 static constexpr size_t kW1M16Bytes = 4 * 2 * 64 * 16;
-size_t layer0_m16_offset(int prec) { return layer_offset(NQA_NUM_CONVS, prec) + regw_bytes(1) + regw_bytes(2); }
 size_t regw_offset(int layer, int prec) {
   size_t o = layer_offset(NQA_NUM_CONVS, prec);
-  if (layer == 2) o += regw_bytes(1);
+  for (int l = kRegwFirst; l < layer; ++l) o += regw_bytes(l);
   return o;
 }
+size_t layer0_m16_offset(int prec) { return regw_offset(kRegwLast + 1, prec); }
 size_t layer_bias_offset(int layer, int prec) {
   const ConvSpec &c = kConvs[layer];
   if (layer == 0) return layer_offset(0, prec) + 27 * 64 * 4;
@@ -269,13 +270,13 @@ int nqa_version(void) { return NQA_VERSION; }
 const char *nqa_last_error(void) { return g_err; }
 
 int nqa_set_conv_variant(int variant) {
-  if (variant < 0 || variant > 31 || (variant & 3) == 3) {
+  if (variant < 0 || variant > 63 || (variant & 3) == 3) {
     set_error("set_conv_variant: unknown variant %d", variant);
     return NQA_E_ARG;
   }
   set_conv_variant(variant & 7);
   set_adists_window_legacy((variant & 8) != 0);
-  set_conv_first_forms((variant >> 4) & 1);
+  set_conv_first_forms((variant >> 4) & 3);
   return NQA_OK;
 }
 
@@ -306,7 +307,7 @@ int nqa_timing_collect(int launches[NQA_K_COUNT], double ms[NQA_K_COUNT]) {
 
 size_t nqa_packed_weights_bytes(int prec) {
   size_t n = layer_offset(NQA_NUM_CONVS, prec);
-  if (prec_valid(prec) && prec_elem_bytes(prec) == 2) n += regw_bytes(1) + regw_bytes(2) + kW1M16Bytes;
+  if (prec_valid(prec) && prec_elem_bytes(prec) == 2) n = layer0_m16_offset(prec) + kW1M16Bytes;
   return n;
 }
 
@@ -404,17 +405,18 @@ int nqa_pack_vgg_weights(const float *const w_host[NQA_NUM_CONVS], const float *
     memcpy(blob + layer_bias_offset(l, prec), b_host[l], (size_t)cs.cout * 4);
   }
   if (prec_elem_bytes(prec) == 2) {
-    for (int l = 1; l <= 2; ++l) {
+    for (int l = kRegwFirst; l <= kRegwLast; ++l) {
       const ConvSpec &cs = kConvs[l];
+      const int nks = cs.cin / 32 * 9;  // k-steps: chunk * 9 + tap
       uint16_t *dst = reinterpret_cast<uint16_t *>(blob + regw_offset(l, prec));
       for (int g = 0; g < cs.cout / 32; ++g)
         for (int i = 0; i < 2; ++i)
-          for (int ks = 0; ks < 18; ++ks)
+          for (int ks = 0; ks < nks; ++ks)
             for (int lane = 0; lane < 64; ++lane)
               for (int j = 0; j < 8; ++j) {
                 const int cout = 32 * g + 16 * i + (lane & 15), cin = 32 * (ks / 9) + 8 * (lane >> 4) + j, t = ks % 9;
                 const float v = w_host[l][((size_t)cout * cs.cin + cin) * 9 + t];
-                dst[((((size_t)g * 2 + i) * 18 + ks) * 64 + lane) * 8 + j] =
+                dst[((((size_t)g * 2 + i) * nks + ks) * 64 + lane) * 8 + j] =
                     prec == NQA_PREC_BF16 ? f32_to_bf16(v) : f32_to_f16(v);
               }
     }

@@ -737,6 +737,178 @@ __global__ __launch_bounds__(512) void conv3x3_regw_kernel(const typename P::T *
 }
 
 // ---------------------------------------------------------------------------------
+// The same for the 128-input-channel layers (conv2_2, conv3_1): ONE wave per SIMD, the whole register file.
+// ---------------------------------------------------------------------------------
+// 32 output channels x 1152 weights are 288 VGPRs -- too many for two waves per SIMD, so a block is 4 waves
+// (launch bound 1 wave per SIMD, up to 512 registers each): wave = one 32-channel group of the block's 128 output
+// channels, ALL 128 pixels of a 4 x 32 tile (4 passes of one tile row = 2 pixel groups).  The halo patch (6 x 34
+// pixels x 4 chunks = 51 KB, 16 one-KB DMA pieces per wave) alternates between two LDS slots, requested one tile
+// ahead; one barrier and one counted vmcnt per tile as in conv3x3_regw_kernel.  Every pixel fragment is read by
+// all four waves (0.5 LDS reads per MFMA again); a tap address serves its four chunks through immediate offsets.
+// Layers with 256 output channels run two such blocks per pixel tile (adjacent tile ids -> the halo hits L2).
+template <typename P, int PF>
+__global__ __launch_bounds__(256, 1) void conv3x3_regw128_kernel(const typename P::T *__restrict__ in,
+                                                                const char *__restrict__ wreg,
+                                                                const float *__restrict__ bias,
+                                                                typename P::T *__restrict__ out, int H, int W, int Cout,
+                                                                int tiles_x, int tiles_y, int total_tiles) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef typename P::T T;
+  constexpr int CIN = 128, NCC = 4, NKS = NCC * 9, TH = 4, TW = 32, HWD = TW + 2, NQ = (TH + 2) * HWD;  // 204
+  constexpr int CH_ITEMS = 1024, CH_BYTES = CH_ITEMS * 16, SLOT = NCC * CH_BYTES;  // 4 DMA rounds of 256 per chunk
+  constexpr int GPP = 2, NPASS = TH, NSTORE = 2 * GPP * NPASS;  // (16 DMA pieces and 16 stores per wave and tile)
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // two halo slots
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // = channel group of the block's 128 channels
+  const int l15 = lane & 15, c4 = lane >> 4;
+  const int nct = Cout / 128;
+
+  const int nblk = gridDim.x, nx = nblk < 8 ? nblk : 8;
+  const int xcd = blockIdx.x % nx, jb = blockIdx.x / nx;
+  const int blk_per_xcd = (nblk - xcd + nx - 1) / nx;
+  const int t_lo = (int)((long)total_tiles * xcd / nx), t_hi = (int)((long)total_tiles * (xcd + 1) / nx);
+  const int my_tiles = t_lo + jb < t_hi ? (t_hi - t_lo - jb - 1) / blk_per_xcd + 1 : 0;
+  if (my_tiles == 0) return;  // (block-uniform)
+  auto tile_coords = [&](int it, int &n, int &x0, int &y0, int &ct) {
+    const int t = t_lo + jb + it * blk_per_xcd;
+    ct = t % nct;  // channel tile fastest: the blocks of one pixel tile are neighbours in time and place
+    const int tp = t / nct;
+    n = tp / (tiles_x * tiles_y);
+    const int t2 = tp - n * (tiles_x * tiles_y), by = t2 / tiles_x;
+    x0 = (t2 - by * tiles_x) * TW;
+    y0 = by * TH;
+  };
+
+  // ---- weights: 2 tiles of 16 channels x 36 k-steps; the channel tile of this block's first tile (re-loaded if a
+  // later tile belongs to another channel tile: with nct = 2 consecutive tiles alternate, so blocks whose stride is
+  // even keep theirs) ----
+  u32x4 wf[2][NKS];
+  float bia[2][4];
+  int cur_ct = -1;
+  auto load_weights = [&](int ct) {
+    const int g = ct * 4 + wave;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks)
+        wf[i][ks] = *reinterpret_cast<const u32x4 *>(wreg + ((((size_t)g * 2 + i) * NKS + ks) * 64 + lane) * 16);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bia[i][e] = bias[g * 32 + i * 16 + 4 * c4 + e];
+    cur_ct = ct;
+  };
+
+  // ---- halo DMA plan: 4 rounds of 256 items per chunk; item j = quarter (j&3)^swz(q) of halo pixel q = j>>2 ----
+  int p_hy[4], p_hx[4], p_c[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int j = r * 256 + tid, q = j >> 2;
+    p_c[r] = (j & 3) ^ lds_swz<true>(q);
+    p_hy[r] = q < NQ ? q / HWD : -100000;
+    p_hx[r] = q - (q / HWD) * HWD;
+  }
+  const unsigned kOOB = 0x80000000u;
+  const unsigned img_in_bytes = (unsigned)H * (unsigned)W * (unsigned)CIN * (unsigned)sizeof(T);
+  const unsigned img_out_bytes = (unsigned)H * (unsigned)W * (unsigned)Cout * (unsigned)sizeof(T);
+  auto issue_halo = [&](int it, int slot_idx) {
+    char *slot = smem + slot_idx * SLOT;
+    const bool real = it < my_tiles;
+    int n = 0, x0 = 0, y0 = 0, ct = 0;
+    if (real) tile_coords(it, n, x0, y0, ct);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T *>(in + (size_t)n * H * W * CIN), 0, img_in_bytes, 0x00020000);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int gy = y0 - 1 + p_hy[r], gx = x0 - 1 + p_hx[r];
+      const bool ok = real && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      const unsigned off = ok ? (unsigned)(((gy * W + gx) * CIN + p_c[r] * 8) * (int)sizeof(T)) : kOOB;
+#pragma unroll
+      for (int cc = 0; cc < NCC; ++cc)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t *)(slot + cc * CH_BYTES + r * 4096 + wave * 1024), 16,
+                                                 off, cc * 64, 0, 0);
+      if (real && !ok && p_hy[r] >= 0) {
+        const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int cc = 0; cc < NCC; ++cc) *reinterpret_cast<u32x4 *>(slot + cc * CH_BYTES + (r * 256 + tid) * 16) = z;
+      }
+    }
+  };
+
+  issue_halo(0, 0);
+  for (int it = 0; it < my_tiles; ++it) {
+    int n, x0, y0, ct;
+    tile_coords(it, n, x0, y0, ct);
+    if (ct != cur_ct) load_weights(ct);  // (block-uniform; compiler-tracked loads)
+    // halo `it` has landed: the only younger operations are the previous tile's stores
+    if (it == 0)
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NSTORE) : "memory");
+    issue_halo(it + 1, (it + 1) & 1);  // that slot was last read during tile it-1
+    const char *slot = smem + (it & 1) * SLOT;
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+        out + (size_t)n * H * W * Cout, 0, img_out_bytes, 0x00020000);
+#pragma unroll 1
+    for (int pass = 0; pass < NPASS; ++pass) {
+      int q0[GPP];
+#pragma unroll
+      for (int g = 0; g < GPP; ++g) q0[g] = pass * HWD + g * 16 + l15;
+      asm volatile("" : "+v"(q0[0]), "+v"(q0[1]));
+      f32x4 acc[2][GPP];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < GPP; ++g) acc[i][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      u32x4 bf[PF + 1][GPP];  // pixel fragments, PF k-steps ahead of the MFMAs
+      auto load_b = [&](int ks, u32x4(&b)[GPP]) {
+        const int cc = ks / 9, t = ks - cc * 9, ky = t / 3, kx = t - ky * 3;
+#pragma unroll
+        for (int g = 0; g < GPP; ++g) {
+          const int q = q0[g] + ky * HWD + kx;
+          b[g] = *reinterpret_cast<const u32x4 *>(slot + cc * CH_BYTES + q * 64 + ((c4 ^ lds_swz<true>(q)) << 4));
+        }
+      };
+#pragma unroll
+      for (int ks = 0; ks < PF; ++ks) load_b(ks, bf[ks]);
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        if (ks + PF < NKS) load_b(ks + PF, bf[(ks + PF) % (PF + 1)]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < GPP; ++g)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            if constexpr (P::ID == NQA_PREC_BF16)
+              acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[i][ks]),
+                                                                  __builtin_bit_cast(bf16x8, bf[ks % (PF + 1)][g]), acc[i][g], 0, 0, 0);
+            else
+              acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wf[i][ks]),
+                                                                 __builtin_bit_cast(f16x8, bf[ks % (PF + 1)][g]), acc[i][g], 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int g = 0; g < GPP; ++g) {
+        const int gy = y0 + pass, gx = x0 + g * 16 + l15;
+        const bool inside = gy < H && gx < W;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          typedef __attribute__((ext_vector_type(4))) T t4;
+          t4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = P::from_f(fmaxf(acc[i][g][e] + bia[i][e], 0.f));
+          const unsigned off =
+              inside ? (unsigned)(((gy * W + gx) * Cout + ct * 128 + wave * 32 + i * 16 + 4 * c4) * (int)sizeof(T)) : kOOB;
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), orsrc, off, 0, 0);
+        }
+      }
+    }
+  }
+#endif
+}
+
+// ---------------------------------------------------------------------------------
 // Stage 1 (conv1_1 + conv1_2) on the same principle, 16-bit modes: the shipped form.
 // ---------------------------------------------------------------------------------
 // conv1_2 is conv3x3_regw_kernel with NCG = 2 (a wave = 32 of the 64 output channels x 2 rows of an 8 x 32 tile,
@@ -1580,12 +1752,16 @@ static int current_device() {
 // another thread's calls launch
 static thread_local int g_conv_variant = 1;  // 0: 4-wave tiles everywhere; 1: + 8-wave 256x256 tiles; 2: + 8-wave 128x512 tiles
 static thread_local int g_stage1_variant = 0;  // 0: persistent two-phase kernel (conv1_fused_kernel); 1: conv1_tile_kernel
+static thread_local int g_no_regw128 = 0;  // 1: conv2_2 / conv3_1 on the implicit GEMM instead of the register-weights kernel (A/B timing)
 static thread_local int g_first_forms = 0;  // 1: the round-1 forms of stage 1 (two-phase kernel) and conv2_1 (implicit GEMM), for A/B timing
 void set_conv_variant(int v) {
   g_conv_variant = v & 3;
   g_stage1_variant = (v >> 2) & 1;
 }
-void set_conv_first_forms(int on) { g_first_forms = on; }
+void set_conv_first_forms(int on) {
+  g_first_forms = on & 1;
+  g_no_regw128 = (on >> 1) & 1;
+}
 
 template <typename P>
 static int launch_conv1_1(const float *x, int n, int H, int W, const char *packed, void *out, hipStream_t st) {
@@ -1652,6 +1828,38 @@ static int launch_regw(const void *in, int n, int H, int W, int layer, const cha
   return check_launch("conv3x3_regw");
 }
 
+// conv2_2 / conv3_1 (Cin 128) with register-resident weights, 16-bit modes; persistent, one 4-wave block per CU
+template <typename P>
+static int launch_regw128(const void *in, int n, int H, int W, int layer, const char *packed, void *out, hipStream_t st) {
+  constexpr int LDS = 2 * 4 * 1024 * 16, PF = 3;  // fragments three k-steps ahead (2: -6 %, 4: equal)
+  static bool attr_done_dev[64] = {false};
+  bool &attr_done = attr_done_dev[current_device() & 63];
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_regw128_kernel<P, PF>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+      set_error("conv3x3_regw128: cannot raise the dynamic LDS limit to %d bytes", LDS);
+      return NQA_E_LAUNCH;
+    }
+    attr_done = true;
+  }
+  const int cus = num_cus();
+  if (!cus) {
+    set_error("conv3x3_regw128: cannot query the device");
+    return NQA_E_LAUNCH;
+  }
+  const int cout = kConvs[layer].cout;
+  const int tiles_x = cdiv(W, 32), tiles_y = cdiv(H, 4), total = n * tiles_x * tiles_y * (cout / 128);
+  int grid = total < cus ? total : cus;
+  if (cout == 256 && grid > 8 && ((grid + 7) / 8) % 2) grid -= 8;  // even stride per XCD class: a block keeps its channel tile
+  const float *bias = reinterpret_cast<const float *>(packed + layer_bias_offset(layer, P::ID));
+  TimedLaunch t(NQA_K_CONV, st);
+  conv3x3_regw128_kernel<P, PF><<<grid, 256, LDS, st>>>(reinterpret_cast<const typename P::T *>(in),
+                                                        packed + regw_offset(layer, P::ID), bias,
+                                                        reinterpret_cast<typename P::T *>(out), H, W, cout, tiles_x,
+                                                        tiles_y, total);
+  return check_launch("conv3x3_regw128");
+}
+
 template <typename P>
 static int launch_conv(const void *in, int n, int H, int W, int layer, const char *packed, void *out, hipStream_t st) {
   const ConvSpec &cs = kConvs[layer];
@@ -1695,6 +1903,8 @@ static int launch_conv(const void *in, int n, int H, int W, int layer, const cha
   if constexpr (sizeof(typename P::T) == 2) {
     // conv2_1: register-resident weights (first-form bit of nqa_set_conv_variant: the implicit GEMM, for A/B runs)
     if (layer == 2 && !g_first_forms && W >= 16) return launch_regw<P>(in, n, H, W, layer, packed, out, st);
+    if ((layer == 3 || layer == 4) && !g_no_regw128 && !g_first_forms && W >= 16)
+      return launch_regw128<P>(in, n, H, W, layer, packed, out, st);
   }
   if (!big) { NQA_GO(2, 2, 2, 2); }                             // 128 ch x 128 px, 4 waves
   NQA_GO(2, 4, 4, 2);                                           // 256 ch x 256 px, 8 waves

@@ -110,7 +110,7 @@ def test_random_conv_layer(layer, n, h, w, prec, np_convs):
     ref = F.relu(F.conv2d(a.float().permute(0, 3, 1, 2), wq, torch.from_numpy(np_convs[layer][1]), padding=1))
     packed = ops.pack_vgg_weights(np_convs, prec).to(dev)
     inp = ops.split16_encode(a.to(dev)) if prec == "f32s" else a.to(dev)
-    for variant in (0, 1, 2, 1 + 16):  # +16: the round-1 forms (conv2_1 on the implicit GEMM)
+    for variant in (0, 1, 2, 1 + 16, 1 + 32):  # +16: the round-1 forms (conv2_1 on the implicit GEMM); +32: register weights on Cin = 128
         ops.set_conv_variant(variant)
         try:
             out = ops.conv3x3_relu(inp, layer, packed, prec)
