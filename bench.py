@@ -102,7 +102,8 @@ def rooflines(ktimes, h, w, b, prec, traffic):
     ach = ig_flops * 2 * b * steps / (ms_ig * 1e-3) / 1e12 if ms_ig > 0 else None
     peak = PEAK_F32_TFLOPS if prec == "f32" else PEAK_F16_TFLOPS
     roof = {
-        "kernel": "conv3x3_igemm_kernel + conv1_fused_kernel (VGG layers 1..12, MFMA implicit GEMM)",
+        "kernel": "VGG conv layers 1..12 on MFMA: conv1_regw_kernel (stage 1), conv3x3_regw_kernel / conv3x3_regw128_kernel "
+                  "(conv2_1 / conv2_2, conv3_1), conv3x3_igemm_kernel (the rest; all layers in f32 / f32s)",
         "bound": "mfma", "achieved": round(ach, 2) if ach else None, "peak": peak, "unit": "TFLOP/s",
         "frac": round(ach / peak, 4) if ach else None,
         "traffic": traffic.get("conv"), "launches": n_ig, "avg_launch_ms": round(ms_ig / n_ig, 5) if n_ig else None,

@@ -1,0 +1,39 @@
+"""The roofline arithmetic of bench.py against the figures SURVEY.md section 8(d) states (no GPU involved)."""
+import importlib.util
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_algorithmic_flops_and_bytes_match_the_survey():
+    b = _bench()
+    ig256, c1_256 = b.conv_flops_per_image(256, 256)
+    ig1080, c1_1080 = b.conv_flops_per_image(1080, 1920)
+    # 40.089 GFLOP per 256x256 image and 1269.295 GFLOP per 1080p image over all 13 layers
+    assert abs((ig256 + c1_256) / 1e9 - 40.089) < 0.01
+    assert abs((ig1080 + c1_1080) / 1e9 - 1269.295) < 0.05
+    # L2-pool row of SURVEY 8(d): 39.3 MB (fp32) per 256x256 image, 1244.3 MB per 1080p image
+    assert abs(b.pool_bytes_per_image(256, 256, 4) / 1e6 - 39.3) < 0.1
+    assert abs(b.pool_bytes_per_image(1080, 1920, 4) / 1e6 - 1244.3) < 0.5
+
+
+def test_workloads_name_the_baseline_configs():
+    b = _bench()
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert "1080" in base["configs"][2] and b.WORKLOADS["1080p"]["B"] == 8 and b.WORKLOADS["1080p"]["H"] == 1080
+    assert b.WORKLOADS["256"]["B"] == 32 and b.WORKLOADS["adists1080p"]["metric"] == "A-DISTS"
+    assert {k for k, _ in b.COMPANIONS} <= set(b.WORKLOADS)
+
+
+def test_committed_traffic_summary_is_readable():
+    b = _bench()
+    t = b.load_traffic()
+    assert t == {} or all("conv" in v and "pool" in v for v in t.values())
