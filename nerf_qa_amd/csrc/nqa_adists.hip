@@ -239,6 +239,32 @@ __device__ inline float wave_sum(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// Three wave sums at once (same adds in the same order as wave_sum, valid in lane 63).  Written as one block of
+// v_add_f32_dpp: left to hipcc each step is a zeroing move + a DPP move + an add, the three chains run one after
+// the other and every DPP waits two states on the add before it (~42 vector instructions and ~15 s_nop per
+// output row); interleaved, the other two chains ARE the two wait states (18 instructions, no s_nop).
+__device__ inline void wave_sum3(float &a, float &b, float &c) {
+#if defined(__HIP_DEVICE_COMPILE__)  // (the host pass would hand the block to the x86 assembler)
+#define NQA_DPP3(CTRL, TAIL)                                        \
+  "v_add_f32_dpp %0, %0, %0 " CTRL " bank_mask:0xf" TAIL "\n\t"     \
+  "v_add_f32_dpp %1, %1, %1 " CTRL " bank_mask:0xf" TAIL "\n\t"     \
+  "v_add_f32_dpp %2, %2, %2 " CTRL " bank_mask:0xf" TAIL "\n\t"
+  asm volatile("s_nop 1\n\t"  // the operands may come straight out of the preceding vector instruction
+               NQA_DPP3("quad_perm:[1,0,3,2] row_mask:0xf", " bound_ctrl:1")
+               NQA_DPP3("quad_perm:[2,3,0,1] row_mask:0xf", " bound_ctrl:1")
+               NQA_DPP3("row_half_mirror row_mask:0xf", " bound_ctrl:1")
+               NQA_DPP3("row_mirror row_mask:0xf", " bound_ctrl:1")
+               NQA_DPP3("row_bcast:15 row_mask:0xa", "")
+               NQA_DPP3("row_bcast:31 row_mask:0xc", "")
+               "s_nop 1"
+               : "+v"(a), "+v"(b), "+v"(c));
+#undef NQA_DPP3
+  a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a), 63));
+  b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, b), 63));
+  c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c), 63));
+#endif
+}
+
 template <typename P, int C>  // C (64..512) is a template parameter so tap strides fold into load immediates
 __global__ __launch_bounds__(256, 2) void adists_window_lanes_kernel(
     const typename P::T *__restrict__ fx, const typename P::T *__restrict__ fy, int H, int W,
@@ -365,20 +391,35 @@ struct WinRing {
 // One input row of the separable window: horizontal 21-tap sums of (x, y, x^2, y^2, xy) into ring slot SLOT
 // (a compile-time constant, so the ring stays in registers and is never rotated); when `full`, the vertical
 // 21-tap sums over the ring -- slot s carries weight kG[(20 - SLOT + s) mod 21] at this phase -- and from them
-// the gamma term (ADISTS.py:84-86), T and S (:182-183) of this lane's channel.  Same operations in the same
-// order as the packed form (bit-identical results).
+// the gamma term (ADISTS.py:84-86), T and S (:182-183) of this lane's channel.
 template <int SLOT>
 __device__ inline void win_row(const float (&x)[kWin], const float (&y)[kWin], WinRing &rg, bool full, float ix,
                                float iy, float wc, float &gterm, float &tt, float &ss) {
-  float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f, h4 = 0.f;
+  // the window is symmetric (kG[j] == kG[20-j]): the centre tap starts the five sums (no zero + fma), every
+  // mirrored pair of taps adds its two samples / squares / products first and takes ONE weighted fma per sum:
+  // 13 operations per pair where tap-by-tap took 14, and no accumulator initialisation
+  constexpr int MID = kWin / 2;
+  static_assert(kWin == 21 && kG[0] == kG[20] && kG[3] == kG[17] && kG[9] == kG[11], "the window must be symmetric");
+  float h0, h1, h2, h3, h4;
+  {
+    const float gx = kG[MID] * x[MID], gy = kG[MID] * y[MID];
+    h0 = gx;
+    h1 = gy;
+    h2 = gx * x[MID];
+    h3 = gy * y[MID];
+    h4 = gx * y[MID];
+  }
 #pragma unroll
-  for (int j = 0; j < kWin; ++j) {
-    const float gx = kG[j] * x[j], gy = kG[j] * y[j];
-    h0 += gx;
-    h1 += gy;
-    h2 = fmaf(gx, x[j], h2);
-    h3 = fmaf(gy, y[j], h3);
-    h4 = fmaf(gx, y[j], h4);
+  for (int j = 0; j < MID; ++j) {
+    const int k = kWin - 1 - j;
+    const float sx = x[j] + x[k], sy = y[j] + y[k];
+    const float uu = fmaf(x[k], x[k], x[j] * x[j]), vv = fmaf(y[k], y[k], y[j] * y[j]);
+    const float ww = fmaf(x[k], y[k], x[j] * y[j]);
+    h0 = fmaf(kG[j], sx, h0);
+    h1 = fmaf(kG[j], sy, h1);
+    h2 = fmaf(kG[j], uu, h2);
+    h3 = fmaf(kG[j], vv, h3);
+    h4 = fmaf(kG[j], ww, h4);
   }
   rg.s0[SLOT] = h0;
   rg.s1[SLOT] = h1;
@@ -386,9 +427,11 @@ __device__ inline void win_row(const float (&x)[kWin], const float (&y)[kWin], W
   rg.s3[SLOT] = h3;
   rg.s4[SLOT] = h4;
   if (full) {
-    float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f;
+    // slot 0 starts the vertical sums (a product, not zero + fma)
+    constexpr float w0 = kG[(kWin - 1 - SLOT) % kWin];
+    float m0 = w0 * rg.s0[0], m1 = w0 * rg.s1[0], m2 = w0 * rg.s2[0], m3 = w0 * rg.s3[0], m4 = w0 * rg.s4[0];
 #pragma unroll
-    for (int sl = 0; sl < kWin; ++sl) {
+    for (int sl = 1; sl < kWin; ++sl) {
       const float wv = kG[(kWin - 1 - SLOT + sl) % kWin];
       m0 = fmaf(wv, rg.s0[sl], m0);
       m1 = fmaf(wv, rg.s1[sl], m1);
@@ -421,10 +464,10 @@ __device__ inline void win_row(const float (&x)[kWin], const float (&y)[kWin], W
 typedef __attribute__((address_space(3))) void lds_void_a_t;
 
 template <typename P, int C>
-__global__ __launch_bounds__(256, 2) void adists_window_lds_kernel(
+__global__ __launch_bounds__(256, 3) void adists_window_lds_kernel(
     const typename P::T *__restrict__ fx, const typename P::T *__restrict__ fy, int H, int W,
     const float *__restrict__ q, int B, int ctot, int coff, const float *__restrict__ wgt, Gauss gw,
-    float *__restrict__ gamma, float *__restrict__ tw, float *__restrict__ sw, int nbx, int nby) {
+    float *__restrict__ gamma, float *__restrict__ tw, float *__restrict__ sw, int nbx, int nby, int strip) {
 #if defined(__HIP_DEVICE_COMPILE__)
   (void)gw;  // the taps are the compile-time constants kG (checked against make_gauss() on the host)
   typedef typename P::T T;
@@ -448,8 +491,10 @@ __global__ __launch_bounds__(256, 2) void adists_window_lds_kernel(
   const int Ho = H - (kWin - 1), Wo = W - (kWin - 1);
   const int ox0 = bx * 4, ox = ox0 + wave;
   const bool live_col = ox < Wo;            // a dead column computes on clamped pixels and stores nothing
-  const int oy0 = by * 64;
-  const int nout = min(64, Ho - oy0);
+  // a block walks a strip of `strip` output rows (the launcher's choice): the 20 rows of vertical run-in are
+  // paid once per strip, so tall strips where the grid stays large enough (64-row strips: 31 % more input rows)
+  const int oy0 = by * strip;
+  const int nout = min(strip, Ho - oy0);
   const int nrows = nout + kWin - 1;
   const size_t st = (size_t)B * ctot, qo = (size_t)b * ctot + coff;
   const unsigned img_bytes = (unsigned)H * (unsigned)W * (unsigned)C * (unsigned)SZ;
@@ -471,10 +516,33 @@ __global__ __launch_bounds__(256, 2) void adists_window_lds_kernel(
   }
   const unsigned row_stride = (unsigned)W * (unsigned)C * (unsigned)SZ;
   const int rd_base = wave * PXB + lane * SZ;  // this lane's tap 0 of image x inside a slot
-  float acc_g = 0.f, acc_t = 0.f, acc_s = 0.f;  // lane l: output row oy0 + l
+  float acc_g = 0.f, acc_t = 0.f, acc_s = 0.f;  // lane l: output row oy0 + 64 k + l of the current 64-row group k
   for (int cb = 0; cb < C; cb += 64) {
     const int c = cb + lane;
-    const float ix = q[0 * st + qo + c], iy = q[1 * st + qo + c], wc = wgt[qo + c];
+    // a finished group of (up to) 64 output rows leaves the lanes: stored by the first channel block, added to
+    // by the later ones (same lane, same address, program order), the last one scales gamma by 1/C
+    auto flush = [&](int orow) {
+      const int r = (orow & ~63) + lane;
+      if (live_col && r <= orow) {
+        const size_t o = ((size_t)b * Ho + oy0 + r) * Wo + ox;
+        float fg = acc_g, ft = acc_t, fs = acc_s;
+        if (cb > 0) {
+          fg += gamma[o];
+          ft += tw[o];
+          fs += sw[o];
+        }
+        gamma[o] = cb + 64 >= C ? fg / (float)C : fg;
+        tw[o] = ft;
+        sw[o] = fs;
+      }
+      acc_g = acc_t = acc_s = 0.f;
+    };
+    // the channel's three constants live in LDS (re-read per output row at immediate offsets): with them in
+    // registers the C > 64 instances need 172 VGPRs, four past the three-waves-per-SIMD limit
+    float *const chan = reinterpret_cast<float *>(smem_w + R * ROWB) + wave * 192 + lane;
+    chan[0] = q[0 * st + qo + c];
+    chan[64] = q[1 * st + qo + c];
+    chan[128] = wgt[qo + c];
     auto issue_row = [&](int r) {
       char *slot = smem_w + (r % R) * ROWB;
 #pragma unroll
@@ -511,14 +579,17 @@ __global__ __launch_bounds__(256, 2) void adists_window_lds_kernel(
       }                                                                                                            \
       float gterm = 0.f, tt = 0.f, ss = 0.f;                                                                       \
       const bool full = rr >= kWin - 1;                                                                            \
-      win_row<SLOT>(xr, yr, rg, full, ix, iy, wc, gterm, tt, ss);                                                  \
+      win_row<SLOT>(xr, yr, rg, full, chan[0], chan[64], chan[128], gterm, tt, ss);                                \
       if (full) {                                                                                                  \
-        const float gs = wave_sum(gterm), ts = wave_sum(tt), sss = wave_sum(ss);                                   \
-        if (lane == rr - (kWin - 1)) {                                                                             \
+        float gs = gterm, ts = tt, sss = ss;                                                                       \
+        wave_sum3(gs, ts, sss);                                                                                    \
+        const int orow = rr - (kWin - 1);                                                                          \
+        if (lane == (orow & 63)) {                                                                                 \
           acc_g += gs;                                                                                             \
           acc_t += ts;                                                                                             \
           acc_s += sss;                                                                                            \
         }                                                                                                          \
+        if ((orow & 63) == 63 || orow == nout - 1) flush(orow);                                                    \
       }                                                                                                            \
     }                                                                                                              \
   }
@@ -528,12 +599,6 @@ __global__ __launch_bounds__(256, 2) void adists_window_lds_kernel(
       NQA_WIN_ROW(14) NQA_WIN_ROW(15) NQA_WIN_ROW(16) NQA_WIN_ROW(17) NQA_WIN_ROW(18) NQA_WIN_ROW(19) NQA_WIN_ROW(20)
     }
 #undef NQA_WIN_ROW
-  }
-  if (live_col && lane < nout) {
-    const size_t o = ((size_t)b * Ho + oy0 + lane) * Wo + ox;
-    gamma[o] = acc_g / (float)C;
-    tw[o] = acc_t;
-    sw[o] = acc_s;
   }
 #endif
 }
@@ -1023,8 +1088,15 @@ static int launch_window_lanes(const void *fx, const void *fy, int B, int H, int
   // the shipped form for float taps (f32 / f32s): taps shared through LDS, XCD-aware column order.  16-bit taps
   // (the opt-in f16 / bf16 modes) measured 20 % slower that way (2-byte LDS reads + conversions) and keep the first form
   if (!adists_window_legacy() && sizeof(typename P::T) == 4) {
-    constexpr int LDS = 4 * 2 * ((int)sizeof(typename P::T) == 4 ? 24 : 32) * 64 * (int)sizeof(typename P::T);
-    const int nbx = cdiv(Wo, 4), nby = cdiv(Ho, 64);
+    // four ring slots + the waves' channel constants (3 x 64 floats each)
+    constexpr int LDS = 4 * 2 * ((int)sizeof(typename P::T) == 4 ? 24 : 32) * 64 * (int)sizeof(typename P::T) + 4 * 768;
+    // strips as tall as the grid allows (up to 256 rows): the fewest strips that still give the chip ~8 rounds
+    // of blocks (3 blocks per CU), else 64-row strips
+    const int nbx = cdiv(Wo, 4);
+    int nby = cdiv(Ho, 256);
+    while (nby < cdiv(Ho, 64) && (long)nbx * nby * B < 6144) ++nby;
+    const int strip = cdiv(Ho, nby);
+    nby = cdiv(Ho, strip);
     const long nblk = (long)nbx * nby * B;
     if (nblk > 0x7FFFFFFFL) {
       set_error("adists_window: grid too large");
@@ -1033,7 +1105,7 @@ static int launch_window_lanes(const void *fx, const void *fy, int B, int H, int
     TimedLaunch t(NQA_K_ADISTS, st);
 #define NQA_WIN(CC)                                                                                                  \
   adists_window_lds_kernel<P, CC><<<(unsigned)nblk, 256, LDS, st>>>(px, py, H, W, q, B, ctot, coff, wgt, g, gamma, \
-                                                                    tw, sw, nbx, nby)
+                                                                    tw, sw, nbx, nby, strip)
     switch (C) {
       case 64: NQA_WIN(64); break;
       case 128: NQA_WIN(128); break;
