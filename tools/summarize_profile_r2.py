@@ -9,7 +9,7 @@ import sys
 
 src, dst = sys.argv[1], sys.argv[2]
 os.makedirs(dst, exist_ok=True)
-CONV = ("conv3x3_igemm_kernel", "conv3x3_regw_kernel", "conv1_regw_kernel", "conv1_fused_kernel", "conv1_tile_kernel")
+CONV = ("conv3x3_igemm_kernel", "conv3x3_regw_kernel", "conv3x3_regw128_kernel", "conv1_regw_kernel", "conv1_fused_kernel", "conv1_tile_kernel")
 
 
 def short(name):
