@@ -131,7 +131,7 @@ __device__ inline void reduce_store(const ShiftedMoments<CPC> &m, double *red, i
 // of y, writes both pooled pixels, and adds the window's lower-right 2x2 (input pixels
 // (2oy..2oy+1, 2ox..2ox+1), each owned by exactly one output pixel) to the sums.
 template <typename P>
-__global__ __launch_bounds__(256) void pool_stats_kernel(const typename P::T *__restrict__ feat,
+__global__ __launch_bounds__(256, 3) void pool_stats_kernel(const typename P::T *__restrict__ feat,
                                                          typename P::T *__restrict__ pooled, int B, int H, int W,
                                                          int C, int Ho, int Wo, int TR, int TC, int tiles_x,
                                                          int nblk, double *__restrict__ part) {
