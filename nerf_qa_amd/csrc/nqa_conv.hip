@@ -194,6 +194,13 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void conv3x3_igemm_kernel(
   // scalar arithmetic + s_mov m0 instead of a VGPR address + v_readfirstlane per DMA
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, h = lane >> 5;
+  // 8-wave tiles: the two waves of a SIMD (w, w+4) run the same loop in the same phase; at different issue
+  // priorities they stop competing instruction by instruction (measured +1.0-1.5 % on layers 5..9 in f16; none in
+  // f32s and none on conv2_1's register-weights kernel, so it is not set there).  NQA_PRIO_SPLIT=0 builds the kernel without it.
+#if !defined(NQA_PRIO_SPLIT)
+#define NQA_PRIO_SPLIT 2
+#endif
+  if (NQA_PRIO_SPLIT && M16 && WAVES_N * WAVES_M == 8 && wave >= 4) __builtin_amdgcn_s_setprio(NQA_PRIO_SPLIT);
   // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so workgroup ids that
   // are equal mod 8 share an L2.  Give each of those classes a contiguous run of pixel tiles so
   // that neighbouring tiles' halo overlap is an L2 hit (speed only; any placement is correct).
@@ -1098,12 +1105,20 @@ __global__ __launch_bounds__(512) void conv1_regw_kernel(const float *__restrict
     const char *slot = smem + (it & 1) * SLOT;
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
         out + (size_t)n * H * W * COUT, 0, img_out_bytes, 0x00020000);
+    constexpr int NSET = 2;  // fragment register sets (three -- two k-steps of lead -- measured neutral to -1 % here)
+    u32x4 bf[NSET][GPP];
+    auto load_b = [&](const int (&q0)[GPP], int ks, u32x4(&b)[GPP]) {
+      const int cc = ks / 9, t = ks - cc * 9, ky = t / 3, kx = t - ky * 3;
+#pragma unroll
+      for (int g = 0; g < GPP; ++g)
+        b[g] = *reinterpret_cast<const u32x4 *>(slot + q0[g] + (cc * CH_BYTES + (ky * HWD + kx) * PITCH));
+    };
+    int q0[GPP];  // byte offset of this lane's fragment at tap (0,0), chunk 0, per 16-pixel group
+#pragma unroll
+    for (int g = 0; g < GPP; ++g) q0[g] = ((ph * RW) * HWD + g * 16 + l15) * PITCH + (c4 << 4);
+    asm volatile("" : "+v"(q0[0]), "+v"(q0[1]));
 #pragma unroll 1
     for (int pass = 0; pass < NPASS; ++pass) {
-      int q0[GPP];  // byte offset of this lane's fragment at tap (0,0), chunk 0, per 16-pixel group
-#pragma unroll
-      for (int g = 0; g < GPP; ++g) q0[g] = ((ph * RW + pass) * HWD + g * 16 + l15) * PITCH + (c4 << 4);
-      asm volatile("" : "+v"(q0[0]), "+v"(q0[1]));
       f32x4 acc[2][GPP];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -1111,17 +1126,11 @@ __global__ __launch_bounds__(512) void conv1_regw_kernel(const float *__restrict
         for (int g = 0; g < GPP; ++g) acc[i][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
       // pixel fragments of k-step ks+1 are read while the MFMAs of ks run (two register sets; a third set, two steps
       // of lead, measured 10 % SLOWER on conv2_1)
-      u32x4 bf[2][GPP];
-      auto load_b = [&](int ks, u32x4(&b)[GPP]) {
-        const int cc = ks / 9, t = ks - cc * 9, ky = t / 3, kx = t - ky * 3;
-#pragma unroll
-        for (int g = 0; g < GPP; ++g)
-          b[g] = *reinterpret_cast<const u32x4 *>(slot + q0[g] + (cc * CH_BYTES + (ky * HWD + kx) * PITCH));
-      };
-      load_b(0, bf[0]);
+      load_b(q0, 0, bf[0]);
+      if (NSET == 3) load_b(q0, 1, bf[1]);
 #pragma unroll
       for (int ks = 0; ks < 18; ++ks) {
-        if (ks + 1 < 18) load_b(ks + 1, bf[(ks + 1) & 1]);
+        if (ks + NSET - 1 < 18) load_b(q0, ks + NSET - 1, bf[(ks + NSET - 1) % NSET]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int g = 0; g < GPP; ++g)
@@ -1129,10 +1138,10 @@ __global__ __launch_bounds__(512) void conv1_regw_kernel(const float *__restrict
           for (int i = 0; i < 2; ++i) {
             if constexpr (P::ID == NQA_PREC_BF16)
               acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[i][ks]),
-                                                                  __builtin_bit_cast(bf16x8, bf[ks & 1][g]), acc[i][g], 0, 0, 0);
+                                                                  __builtin_bit_cast(bf16x8, bf[ks % NSET][g]), acc[i][g], 0, 0, 0);
             else
               acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wf[i][ks]),
-                                                                 __builtin_bit_cast(f16x8, bf[ks & 1][g]), acc[i][g], 0, 0, 0);
+                                                                 __builtin_bit_cast(f16x8, bf[ks % NSET][g]), acc[i][g], 0, 0, 0);
           }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -1150,6 +1159,9 @@ __global__ __launch_bounds__(512) void conv1_regw_kernel(const float *__restrict
           __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), orsrc, off, 0, 0);
         }
       }
+#pragma unroll
+      for (int g = 0; g < GPP; ++g) q0[g] += HWD * PITCH;  // next tile row
+      asm volatile("" : "+v"(q0[0]), "+v"(q0[1]));
     }
   };
   for (int it = 0; it < my_tiles; ++it) {
@@ -1164,10 +1176,16 @@ __global__ __launch_bounds__(512) void conv1_regw_kernel(const float *__restrict
 #else
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {  // (a loop, so that each phase's code exists once)
-      if ((half == 0) == (wave < 4))
+      // conv1_1 is a latency chain (LDS read -> 8 MFMAs -> convert -> LDS write, three groups in flight): at a
+      // higher issue priority its few instructions go out the moment they are ready and the partner wave's
+      // conv1_2 fills every other slot (2.70 -> 2.59 ms at 1080p, 409 -> 386 us at 256 x 256; priority 3: 2.65)
+      if ((half == 0) == (wave < 4)) {
+        __builtin_amdgcn_s_setprio(0);
         conv1_2_tile(it);
-      else if (next)
+      } else if (next) {
+        __builtin_amdgcn_s_setprio(2);
         conv1_1_halo(it + 1);
+      }
     }
 #endif
     raw_commit(it & 1);  // tile it+2's patch; patch it&1 was last read by conv1_1 of tile `it`, during tile it-1
