@@ -214,7 +214,7 @@ def run_workload(key, precision, steps, warmup, dev, world, rank, batch=0):
         if world > 1:  # warm the collective too
             sharding.gather_scores(scores, world * scores.numel())
         sync()
-        ops.timing_enable(True)
+        ops.timing_enable(not os.environ.get("NQA_BENCH_NO_EVENTS"))  # (development: what the event pairs cost)
         t0 = time.perf_counter()
         for k in range(steps):
             scores[k * B:(k + 1) * B] = model(x, y)

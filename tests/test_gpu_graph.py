@@ -1,0 +1,37 @@
+"""The fused C-ABI entry points under HIP stream capture: they only enqueue (kernels and async memsets on the stream they
+are handed, no synchronisation, no allocation), so a whole DISTS / A-DISTS forward can be captured into a hipGraph once
+and replayed on new frames -- the launch-bound case (small frames, B=1) that HIP graphs are for."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("metric", ["DISTS", "ADISTS"])
+def test_forward_captures_into_a_hip_graph_and_replays(metric):
+    from nerf_qa_amd.ADISTS import ADISTS
+    from nerf_qa_amd.DISTS_pytorch import DISTS
+    dev = torch.device("cuda:0")
+    model = (DISTS() if metric == "DISTS" else ADISTS()).to(dev).eval()
+    call = (lambda a, b: model(a, b, batch_average=False)) if metric == "DISTS" else (lambda a, b: model(a, b, as_loss=False))
+    gen = torch.Generator(device=dev).manual_seed(7)
+    frames = [torch.rand(2, 3, 128, 160, device=dev, generator=gen) for _ in range(4)]
+    x, y = frames[0].clone(), frames[1].clone()  # the graph's static inputs
+    with torch.no_grad():
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):  # warm-up outside capture: workspace, function attributes, device queries
+            for _ in range(2):
+                call(x, y)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = call(x, y)
+        for a, b in ((frames[0], frames[1]), (frames[2], frames[3]), (frames[3], frames[0])):
+            x.copy_(a)
+            y.copy_(b)
+            graph.replay()
+            torch.cuda.synchronize(dev)
+            got = out.clone()
+            want = call(a, b)
+            assert torch.equal(got, want), (metric, (got - want).abs().max().item())
