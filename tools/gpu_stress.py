@@ -53,6 +53,6 @@ for i in range(N):
     # its tail is the reason `auto` switches to f32s, and the value is just recorded
     assert (e16 <= 1e-4 or h * w < 96 * 96) and e32 <= 5e-6, (h, w, b, e16, e32)
     worst = {"f16": max(worst["f16"], e16), "f32s": max(worst["f32s"], e32), "a32s": max(worst["a32s"], ea)}
-    if i % 25 == 24:
-        print(i + 1, worst, flush=True)
+    if i % 25 == 24 or HI > 400:  # (large frames: a line per case, minutes apart)
+        print(i + 1, (h, w, b), worst, flush=True)
 print("done", N, worst, "A-DISTS cases above 1e-4:", flips)
