@@ -18,3 +18,14 @@ for name, fn, bytes_ in (("copy (read + write)", lambda: b.copy_(a), 2 * a.numel
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 10
     print(f"{name}: {ms:.3f} ms, {bytes_ / ms / 1e9:.2f} TB/s", flush=True)
+c = torch.empty(1 << 31, dtype=torch.float32, device=dev)  # 8 GiB: the size of conv1_1's f32s output at 1080p B=8
+for _ in range(2):
+    c.zero_()
+torch.cuda.synchronize()
+e0.record()
+for _ in range(5):
+    c.zero_()
+e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 5
+print(f"fill (write only): {ms:.3f} ms, {c.numel() * 4 / ms / 1e9:.2f} TB/s", flush=True)
