@@ -5,6 +5,10 @@
                   [--precision f16|f32s|f32|bf16] [--only]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts that torch.distributed.run
+command itself as a CHILD process (before anything touches the GPU), relays rank 0's JSON line and exits with the
+child's code; under an external launcher (WORLD_SIZE set) it is one of the N ranks.
+
 The line's `value` is the headline workload, BASELINE.json configs[2]: B=8 pairs of 1920x1080 per GPU per
 step through DISTS.forward in its shipped precision (f16 MFMA convolutions), frames resident in HBM.  Frames
 shard across ranks with no data-path collective; the only exchange is ONE all-gather of the per-frame scores
@@ -29,7 +33,9 @@ container) on a bounded sample of the headline workload on this box's host cores
 import argparse
 import json
 import os
+import socket
 import statistics
+import subprocess
 import sys
 import time
 
@@ -262,12 +268,60 @@ def run_video(n_frames, precision, warmup, dev, world, rank, batch):
     return dt, ktimes, prec, H, W, src, {k: float(v) for k, v in cols.items()}
 
 
+def self_launch(n, argv):
+    """`python bench.py --gpus N` typed as is: run the N ranks under torch.distributed.run as a child process
+    (never exec: nothing here has touched the GPU yet, and nothing will in this process), relay rank 0's JSON
+    line on stdout (everything else the ranks print goes to stderr) and return the child's exit code."""
+    with socket.socket() as sk:  # a free rendezvous port
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True)
+    for line in proc.stdout:
+        if line.startswith('{"metric"'):
+            sys.stdout.write(line)
+            sys.stdout.flush()
+        else:
+            sys.stderr.write(line)
+    return proc.wait()
+
+
+def run_stub(steps, warmup, world, rank):
+    """`--workload stub` (tests only, never a bench number): the launch / timing / all-gather skeleton of
+    run_workload on CPU tensors with a placeholder per-pair score, so the N > 1 path of THIS file can be
+    exercised under gloo on a box without a GPU (tests/test_bench_launch.py).  No HIP kernel runs."""
+    B = 8
+    g = torch.Generator().manual_seed(1000 + rank)
+    x = torch.rand(B, 3, 32, 32, generator=g)
+    y = (x + 0.1 * torch.randn(B, 3, 32, 32, generator=g)).clamp_(0, 1)
+    model = lambda a, b: (a - b).abs().mean((1, 2, 3))  # noqa: E731
+    scores = torch.empty(steps * B)
+    for _ in range(warmup):
+        model(x, y)
+    if world > 1:
+        sharding.gather_scores(scores, world * scores.numel())
+        dist.barrier()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        scores[k * B:(k + 1) * B] = model(x, y)
+    all_scores = sharding.gather_scores(scores, world * scores.numel()) if world > 1 else scores
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    assert all_scores.numel() == world * steps * B and torch.isfinite(all_scores).all()
+    return dt, B
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="1080p",
+    ap.add_argument("--workload", choices=sorted(WORKLOADS) + ["stub"], default="1080p",
                     help="1080p (default, BASELINE configs[2]) | 256 | adists1080p | adists256 | video10k")
     ap.add_argument("--precision", default=None, help="f16 (DISTS default), f32s (A-DISTS default), f32, bf16")
     ap.add_argument("--only", action="store_true", help="skip the companion workloads of the N=1 line")
@@ -276,28 +330,32 @@ def main():
     ap.add_argument("--frames", type=int, default=10000, help="frames of the video10k workload")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # typed as `python bench.py --gpus N`: become the launcher (no GPU call has been made in this process)
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
-    # one rank per GPU; the modulo only matters when the N>1 path is rehearsed on a 1-GPU box
-    # (NQA_DIST_BACKEND=gloo, several ranks sharing cuda:0)
-    dev_index = local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE={world})")
+    stub = args.workload == "stub"
+    if stub:
+        dev = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
+        # one rank per GPU; the modulo only matters when the N>1 path is rehearsed on a 1-GPU box
+        # (NQA_DIST_BACKEND=gloo, several ranks sharing cuda:0)
+        dev_index = local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(dev_index)
+        dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("NQA_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
+        backend = "gloo" if stub else os.environ.get("NQA_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-
-    traffic = load_traffic()
-    wl = WORKLOADS[args.workload]
 
     def rank_times(dt):
         """(max over ranks, per-rank list) of a rank's wall time (one all_gather_into_tensor, as for the scores)."""
@@ -308,6 +366,23 @@ def main():
         dist.all_gather_into_tensor(allt, t)
         per = [float(v) for v in allt.cpu().tolist()]
         return max(per), per
+
+    if stub:
+        dt, B = run_stub(args.steps, args.warmup, world, rank)
+        dt, per = rank_times(dt)
+        if rank == 0:
+            print(json.dumps({"metric": "stub frame-pairs/s (launch-path test only, no HIP kernel ran)",
+                              "value": round(world * B * args.steps / dt, 2), "unit": "frame-pairs/s", "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+                              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                              "data": "synthetic", "config": {"workload": "stub"},
+                              "per_rank_pairs_per_s": [round(B * args.steps / t, 2) for t in per]}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    traffic = load_traffic()
+    wl = WORKLOADS[args.workload]
 
     if args.workload == "video10k":
         batch = args.batch or wl["B"]
