@@ -87,8 +87,16 @@ class ADISTS(torch.nn.Module):
 
     def __getstate__(self):
         d = self.__dict__.copy()
-        d["_packed"], d["_packed_key"], d["_ws"] = None, None, ops.Workspace()
+        for k in ("_packed", "_packed_key", "_ws"):  # device scratch never travels (__setstate__ rebuilds it)
+            d.pop(k, None)
         return d
+
+    def __setstate__(self, state):  # also a module pickled by the reference's class (install_alias())
+        super().__setstate__(state)
+        d = self.__dict__
+        d.setdefault("precision", os.environ.get("NQA_ADISTS_PRECISION", DEFAULT_PRECISION))
+        d.setdefault("vgg_source", "unpickled module (Conv2d weights of stage1..5)")
+        d["_packed"], d["_packed_key"], d["_ws"] = None, None, ops.Workspace()
 
     def forward_once(self, x):
         taps = ops.vgg_pyramid(x, self._packed_weights(x.device), self.precision, self._ws)
@@ -110,3 +118,9 @@ class ADISTS(torch.nn.Module):
         if as_loss:
             return 1 - d.mean()
         return 1 - d
+
+
+def prepare_image(image, resize=True):
+    """PIL image -> float32 (1,3,H,W) in [0,1]; ADISTS.py:200-204 (short side to 256, aspect ratio kept)."""
+    from ..DISTS_pytorch.DISTS_pt import prepare_image as _p
+    return _p(image, resize=resize, keep_aspect_ratio=True)

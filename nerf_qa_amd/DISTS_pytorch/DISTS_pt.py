@@ -132,8 +132,19 @@ class DISTS(torch.nn.Module):
 
     def __getstate__(self):  # torch.save(model) (run_nerf_qa.py:502): drop device scratch
         d = self.__dict__.copy()
-        d["_packed"], d["_ws"] = {}, ops.Workspace()
+        d.pop("_packed", None)
+        d.pop("_ws", None)  # (__setstate__ rebuilds both)
         return d
+
+    def __setstate__(self, state):
+        """Also accepts a module pickled by the REFERENCE's class of this name (loaded through
+        nerf_qa_amd.install_alias(); reeval.py:83): its stage1..5 carry the Conv2d weights, the private fields
+        of this build are filled in here."""
+        super().__setstate__(state)
+        d = self.__dict__
+        d.setdefault("precision", os.environ.get("NQA_PRECISION", DEFAULT_PRECISION))
+        d.setdefault("vgg_source", "unpickled module (Conv2d weights of stage1..5)")
+        d["_packed"], d["_ws"] = {}, ops.Workspace()
 
     def _similarities(self, x, y):
         if x.shape != y.shape:

@@ -12,6 +12,7 @@ import torch
 
 from ..config import config
 from .DISTS_pt import _DATA, DISTS as _BaseDISTS
+from .DISTS_pt import L2pooling  # noqa: F401  (the reference defines it in this module too: pickles name it)
 
 
 class DISTS(_BaseDISTS):
