@@ -28,8 +28,16 @@ def models(dev):
         m = {"f16": DISTS(precision="f16").to(dev).eval(), "f32": DISTS(precision="f32").to(dev).eval(),
              "a16": ADISTS(precision="f16").to(dev).eval(), "a32": ADISTS(precision="f32").to(dev).eval(),
              "a32s": ADISTS(precision="f32s").to(dev).eval(), "f32s": DISTS(precision="f32s").to(dev).eval()}
-        d = DISTS()  # the shipped defaults: f16 convolutions from 96x96 pixels up, f32s below; A-DISTS always f32s
-        assert d.precision == "auto" and d.precision_for(256, 256) == "f16" and d.precision_for(64, 64) == "f32s"
+        # the shipped defaults: DISTS "auto" = f32s below 96x96 pixels and, above, f16 when the one-time calibration of
+        # the module's VGG weights allows it (the gain-1.0 stand-ins do); A-DISTS always f32s
+        d = DISTS().to(dev)
+        assert d.precision == "auto" and d.precision_for(64, 64) == "f32s"
+        rep = d.calibrate(dev)
+        print("auto calibration:", rep)
+        assert rep["choice"] == "f16" and rep["max_abs_diff"] <= rep["budget"] == 4e-5
+        assert d.precision_for(256, 256) == "f16" and d.precision_for(1080, 1920) == "f16"
+        with pytest.raises(Exception):
+            DISTS().precision_for(256, 256)  # on the CPU there is nothing to calibrate on
         assert ADISTS().precision == "f32s"
         return m
 

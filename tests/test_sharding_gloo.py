@@ -78,3 +78,50 @@ def test_gather_without_process_group():
     from nerf_qa_amd.sharding import gather_scores
     t = torch.arange(5, dtype=torch.float32)
     assert torch.equal(gather_scores(t, 5), t)
+
+
+def _video_worker(rank, world, port, n_frames, batch, h, w, q):
+    """configs[3]'s own frame source (video.synthetic_frames, seed = frame index) under the sharded loop."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nerf_qa_amd import sharding, video
+    cpu = torch.device("cpu")
+    seen = []
+
+    def score_batch(lo, hi):
+        ref, ren = video.synthetic_frames(range(lo, hi), h, w, cpu)
+        seen.append((lo, hi))
+        return (ref - ren).abs().mean((1, 2, 3)) + ref[:, 0, 0, 0]  # any pure function of the two frames
+
+    full = sharding.score_frames_sharded(score_batch, n_frames, batch, cpu)
+    q.put((rank, full.numpy(), seen))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_frames,batch", [(21, 4), (16, 8), (5, 8)], ids=["21x4_uneven", "16x8", "5x8_short_rank"])
+def test_synthetic_video_sharded_world2(n_frames, batch):
+    """Shard boundaries and per-frame seeds: two ranks generating their own frame ranges produce, after the one
+    all-gather, exactly the vector a single process gets from frames 0..N-1 (BASELINE configs[3], prep.py:181-198)."""
+    from nerf_qa_amd import video
+    h, w = 16, 24
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_video_worker, args=(r, 2, port, n_frames, batch, h, w, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref, ren = video.synthetic_frames(range(n_frames), h, w, torch.device("cpu"))
+    want = ((ref - ren).abs().mean((1, 2, 3)) + ref[:, 0, 0, 0]).numpy()
+    assert len(set(np.round(want, 6))) == n_frames  # every frame is its own
+    for rank, full, seen in results:
+        assert np.array_equal(full, want), rank
+        lo, hi = min(s[0] for s in seen) if seen else 0, max(s[1] for s in seen) if seen else 0
+        per = -(-n_frames // 2)
+        assert (lo, hi) == (min(n_frames, rank * per), min(n_frames, (rank + 1) * per)) or not seen
+    cols = video.video_columns("DISTS", results[0][1])
+    assert cols["DISTS"].dtype == np.float32 and abs(float(cols["DISTS"]) - float(np.mean(want))) < 1e-7
