@@ -1,7 +1,9 @@
 """Build libnqa_hip.so in-tree with hipcc for gfx950 (no torch headers, plain C ABI)."""
 from __future__ import annotations
 
+import json
 import os
+import re
 import subprocess
 import sys
 
@@ -10,7 +12,45 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libnqa_hip.so")
 SOURCES = ["nqa_api.hip", "nqa_conv.hip", "nqa_pool_stats.hip", "nqa_adists.hip", "nqa_prep.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+         "-Rpass-analysis=kernel-resource-usage"]  # the remarks are parsed below: no hand-scheduled kernel may spill
+RESOURCES = os.path.join(HERE, "kernel_resources.json")
+# Kernels whose schedule is written against an exact register budget and counted vmcnt waits (scratch traffic shares
+# the vmcnt counter with the LDS-DMA rings, so a spill makes every counted wait over-wait): a build in which one of
+# these uses scratch FAILS.  Matched against the demangled-ish kernel name in the compiler's remark.
+NO_SCRATCH = ("conv3x3_igemm_kernel", "conv3x3_regw_kernel", "conv3x3_regw128_kernel", "conv1_regw_kernel",
+              "conv1_fused_kernel", "conv1_tile_kernel", "conv1_split_kernel", "pool_stats_kernel",
+              "adists_window_lds_kernel", "adists_window_planar_kernel", "l2pool_kernel", "stats_nhwc_kernel")
+
+
+def parse_resource_remarks(text: str) -> dict:
+    """hipcc -Rpass-analysis=kernel-resource-usage -> {mangled kernel name: {"vgprs", "agprs", "sgprs", "scratch",
+    "occupancy", "lds"}} (one block of remarks per kernel, `Function Name:` first)."""
+    out, cur = {}, None
+    keys = {"VGPRs": "vgprs", "AGPRs": "agprs", "SGPRs": "sgprs", "ScratchSize [bytes/lane]": "scratch",
+            "Occupancy [waves/SIMD]": "occupancy", "LDS Size [bytes/block]": "lds"}
+    for line in text.splitlines():
+        m = re.search(r"remark: [^:]*:\d+:\d+: +(.*?) \[-Rpass-analysis", line) or \
+            re.search(r"remark: +(.*?) \[-Rpass-analysis", line)
+        if not m:
+            continue
+        body = m.group(1).strip()
+        if body.startswith("Function Name:"):
+            cur = out.setdefault(body.split(":", 1)[1].strip(), {})
+        elif cur is not None and ":" in body:
+            k, v = body.rsplit(":", 1)
+            if k.strip() in keys:
+                try:
+                    cur[keys[k.strip()]] = int(v)
+                except ValueError:
+                    pass
+    return out
+
+
+def check_no_scratch(res: dict) -> list:
+    return sorted(f"{name}: {r['scratch']} bytes/lane of scratch ({r.get('vgprs')} VGPRs)" for name, r in res.items()
+                  if r.get("scratch", 0) and any(k in name for k in NO_SCRATCH))
+
 # nqa_adists.hip: the window kernels' tap arithmetic is written as scalar float FMAs with literal-constant weights
 # (v_fmac_f32 with a 32-bit immediate); the SLP vectorizer would pair them into v_pk_*_f32, which issue at half
 # rate on gfx950 and need a {w, w} register pair built per tap
@@ -45,15 +85,26 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str |
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
         objs.append(obj)
     failed = False
+    resources = {}
     for src, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             failed = True
-            sys.stderr.write(f"hipcc failed on {src}:\n{out}\n")
-        elif verbose and out.strip():
-            print(out)
+            sys.stderr.write(f"hipcc failed on {src}:\n" + "\n".join(
+                ln for ln in out.splitlines() if "-Rpass-analysis" not in ln) + "\n")
+            continue
+        resources.update(parse_resource_remarks(out))
+        rest = "\n".join(ln for ln in out.splitlines() if "-Rpass-analysis" not in ln)
+        if verbose and rest.strip():
+            print(rest)
     if failed:
         raise RuntimeError("libnqa_hip.so: compilation failed")
+    spills = check_no_scratch(resources)
+    if spills and not extra_flags:  # (timing-only ablation builds may do what they like)
+        raise RuntimeError("libnqa_hip.so: hand-scheduled kernels spill to scratch:\n  " + "\n  ".join(spills))
+    if not variant:
+        with open(RESOURCES, "w") as f:
+            json.dump({k: resources[k] for k in sorted(resources)}, f, indent=0)
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib]
     subprocess.run(cmd, check=True)
     if variant:  # a development variant's objects are not reused: do not let them pile up

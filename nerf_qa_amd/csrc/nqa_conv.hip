@@ -22,6 +22,8 @@
 // Three more kernels live here: conv1_fused_kernel and conv1_tile_kernel (stage 1 without its HBM
 // intermediate, two forms) and the precision variants of the implicit GEMM (f32: exact-f32 MFMA;
 // f32s: split-f16 products on split16 activations; 16-bit: v_mfma_f32_16x16x32).
+#include <atomic>
+
 #include "nqa_common.h"
 
 namespace nqa {
@@ -1795,8 +1797,8 @@ template <typename P, int WAVES_N, int WAVES_M, int WN_T, int WM_T, int TW, bool
 static int launch_igemm(const void *in, int n, int H, int W, int cin, int cout, const char *wpk, const float *bias,
                         void *out, int out_split, hipStream_t st) {
   typedef ConvGeom<WAVES_N, WAVES_M, WN_T, WM_T, TW> G;
-  static bool attr_done_dev[64] = {false};  // the attribute is per device: a process may drive several
-  bool &attr_done = attr_done_dev[current_device() & 63];
+  static std::atomic<bool> attr_done_dev[64];  // the attribute is per device: a process may drive several
+  std::atomic<bool> &attr_done = attr_done_dev[current_device() & 63];
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_igemm_kernel<P, WAVES_N, WAVES_M, WN_T, WM_T, TW, M16>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES) != hipSuccess) {
@@ -1821,8 +1823,8 @@ static int num_cus();
 template <typename P>
 static int launch_regw(const void *in, int n, int H, int W, int layer, const char *packed, void *out, hipStream_t st) {
   constexpr int LDS = 3 * 2 * 1536 * 16;
-  static bool attr_done_dev[64] = {false};
-  bool &attr_done = attr_done_dev[current_device() & 63];
+  static std::atomic<bool> attr_done_dev[64];
+  std::atomic<bool> &attr_done = attr_done_dev[current_device() & 63];
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_regw_kernel<P, 4>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
@@ -1850,8 +1852,8 @@ static int launch_regw(const void *in, int n, int H, int W, int layer, const cha
 template <typename P>
 static int launch_regw128(const void *in, int n, int H, int W, int layer, const char *packed, void *out, hipStream_t st) {
   constexpr int LDS = 2 * 4 * 1024 * 16, PF = 3;  // fragments three k-steps ahead (2: -6 %, 4: equal)
-  static bool attr_done_dev[64] = {false};
-  bool &attr_done = attr_done_dev[current_device() & 63];
+  static std::atomic<bool> attr_done_dev[64];
+  std::atomic<bool> &attr_done = attr_done_dev[current_device() & 63];
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_regw128_kernel<P, PF>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
@@ -1931,22 +1933,24 @@ static int launch_conv(const void *in, int n, int H, int W, int layer, const cha
 
 // compute units of the current device (cached per device: a process may drive several)
 static int num_cus() {
-  static int cus[64] = {0};
+  static std::atomic<int> cus[64];  // (concurrent first calls both query and store the same value)
   const int dev = current_device() & 63;
-  if (!cus[dev]) {
+  int n = cus[dev].load(std::memory_order_relaxed);
+  if (!n) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-    cus[dev] = prop.multiProcessorCount;
+    n = prop.multiProcessorCount;
+    cus[dev].store(n, std::memory_order_relaxed);
   }
-  return cus[dev];
+  return n;
 }
 
 template <typename P>
 static int launch_conv1_fused(const float *x, const float *y, int B, int n, int H, int W, const char *packed,
                               void *out, hipStream_t st) {
   constexpr int LDS = Conv1Fused::LDS_BYTES;
-  static bool attr_done_dev[64] = {false};  // the attribute is per device: a process may drive several
-  bool &attr_done = attr_done_dev[current_device() & 63];
+  static std::atomic<bool> attr_done_dev[64];  // the attribute is per device: a process may drive several
+  std::atomic<bool> &attr_done = attr_done_dev[current_device() & 63];
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv1_fused_kernel<P>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
@@ -1977,8 +1981,8 @@ static int launch_conv1_tile(const float *x, const float *y, int B, int n, int H
                              hipStream_t st) {
   typedef Conv1Tile::G G;
   constexpr int LDS = Conv1Tile::LDS_BYTES;
-  static bool attr_done_dev[64] = {false};  // the attribute is per device: a process may drive several
-  bool &attr_done = attr_done_dev[current_device() & 63];
+  static std::atomic<bool> attr_done_dev[64];  // the attribute is per device: a process may drive several
+  std::atomic<bool> &attr_done = attr_done_dev[current_device() & 63];
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv1_tile_kernel<P>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
@@ -2003,8 +2007,8 @@ template <typename P>
 static int launch_conv1_regw(const float *x, const float *y, int B, int n, int H, int W, const char *packed, void *out,
                              hipStream_t st) {
   constexpr int LDS = 2 * 2 * 352 * 96 + 2 * 13 * 40 * 8 + 4 * 2 * 64 * 16 + 256;
-  static bool attr_done_dev[64] = {false};
-  bool &attr_done = attr_done_dev[current_device() & 63];
+  static std::atomic<bool> attr_done_dev[64];
+  std::atomic<bool> &attr_done = attr_done_dev[current_device() & 63];
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv1_regw_kernel<P>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {

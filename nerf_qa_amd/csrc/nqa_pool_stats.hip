@@ -130,8 +130,10 @@ __device__ inline void reduce_store(const ShiftedMoments<CPC> &m, double *red, i
 // channel group and walks the strip.  For each output pixel it loads the 3x3 window of x and
 // of y, writes both pooled pixels, and adds the window's lower-right 2x2 (input pixels
 // (2oy..2oy+1, 2ox..2ox+1), each owned by exactly one output pixel) to the sums.
+// (three blocks per CU for the float instances, 128 VGPRs; the 16-bit instances need 176 with the row-reuse
+// registers and would spill 12 B/lane at three -- they run two blocks per CU, which measured the same at 1080p)
 template <typename P>
-__global__ __launch_bounds__(256, 3) void pool_stats_kernel(const typename P::T *__restrict__ feat,
+__global__ __launch_bounds__(256, sizeof(typename P::T) == 2 ? 2 : 3) void pool_stats_kernel(const typename P::T *__restrict__ feat,
                                                          typename P::T *__restrict__ pooled, int B, int H, int W,
                                                          int C, int Ho, int Wo, int TR, int TC, int tiles_x,
                                                          int nblk, double *__restrict__ part) {

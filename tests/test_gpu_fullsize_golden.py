@@ -68,25 +68,25 @@ def test_dists_b32_256_vs_reference(gain, dev):
     assert x.shape[0] == 32
     # THE GATE: the shipped default ("auto") within 1e-4 of the reference on every pinned weight set.  auto calibrates
     # f16 against f32s once with the weights at hand (DISTS_pt.py header): gain 1.0 runs in f16, the gains whose
-    # activations grow faster with depth measure above the 4e-5 budget and run in f32s.
+    # activations grow faster with depth measure above the budget (rms 2e-5 / max 6e-5 on 128 pairs) and run in f32s.
     m = DISTS(vgg16_path=_spec(gain)).to(dev).eval()
     assert m.precision == "auto"
     rep = m.calibrate(dev)
     with torch.no_grad():
         got = m(x, y).cpu().numpy()
     err = np.abs(got - g["score"]).max()
-    print(f"\nDISTS B=32 256x256 gain {gain} DEFAULT (auto -> {rep['choice']}; calibration max|f16-f32s| = "
-          f"{rep['max_abs_diff']:.2e}, budget {rep['budget']:.0e}): max|dscore|={err:.2e}")
+    print(f"\nDISTS B=32 256x256 gain {gain} DEFAULT (auto -> {rep['choice']}; calibration |f16-f32s| max "
+          f"{rep['max_abs_diff']:.2e} rms {rep['rms_diff']:.2e}): max|dscore|={err:.2e}")
     assert err <= 1e-4, ("auto", rep, gain, err)
     assert rep["choice"] == ("f16" if gain == 1.0 else "f32s"), rep  # (what the three pinned sets are known to measure)
     del m
     # per-channel S1 / S2 are quotients with c = 1e-6: on nearly dead channels (variance ~1e-6) a 1e-9 difference in
     # a moment moves S2 by 1e-3, so they get a loose bound; the score (their alpha/beta-weighted sum) is the bar.
     # Explicitly named modes: f32s / f32 to 5e-6.  Forced f16 (opt-in fast mode) is held to 1e-4 where auto would
-    # choose it too and where it has margin (gains 1.0, 1.3); at gain 1.6 it is OUT OF SPEC by construction (a pair's
-    # error is noise of sigma ~3.5e-5, the largest of 32 lands at 0.85e-4..1.2e-4) -- that is why auto does not choose
-    # it there; the value is printed, not gated (only a sanity bound).
-    for prec, tol, stol in (("f16", 1e-4 if gain <= 1.3 else None, None), ("f32s", 5e-6, 2e-2), ("f32", 5e-6, 2e-2)):
+    # chooses it (gain 1.0); at gains 1.3 / 1.6 it is OUT OF SPEC by construction (heavy-tailed error: this batch
+    # lands at 6e-5 / 1e-4, other seeds at 1.3e-4 / 2e-4, tools/gpu_auto_calibration.py) -- that is why auto does not
+    # choose it there; the value is printed, not gated (only a sanity bound).
+    for prec, tol, stol in (("f16", 1e-4 if gain == 1.0 else None, None), ("f32s", 5e-6, 2e-2), ("f32", 5e-6, 2e-2)):
         m = DISTS(precision=prec, vgg16_path=_spec(gain)).to(dev).eval()
         with torch.no_grad():
             got = m(x, y).cpu().numpy()
@@ -95,7 +95,7 @@ def test_dists_b32_256_vs_reference(gain, dev):
         e1, e2 = np.abs(s1 - g["s1"]).max(), np.abs(s2 - g["s2"]).max()
         print(f"\nDISTS B=32 256x256 gain {gain} {prec}: max|dscore|={err:.2e} max|dS1|={e1:.2e} max|dS2|={e2:.2e} "
               f"(scores {g['score'].min():.4f}..{g['score'].max():.4f})"
-              + ("" if tol else "   [forced f16 at gain 1.6: out of spec, not chosen by auto]"))
+              + ("" if tol else "   [forced f16 at this gain: out of spec, not chosen by auto]"))
         assert err <= (tol if tol else 5e-4), (prec, gain, err)
         if stol:
             assert e1 <= stol and e2 <= stol, (prec, gain, e1, e2)
