@@ -46,8 +46,16 @@ extern "C" {
 
 /* NQA_PREC_F32S: float32 activations like NQA_PREC_F32, but conv layers 2..13 multiply on the f16
  * matrix cores with both operands split into (hi, lo) half pairs (3 MFMAs per product block,
- * ~2^-21 relative error per product) -- near-f32 results at a fraction of the f32-MFMA cost. */
-enum { NQA_PREC_F32 = 0, NQA_PREC_BF16 = 1, NQA_PREC_F16 = 2, NQA_PREC_F32S = 3 };
+ * ~2^-21 relative error per product) -- near-f32 results at a fraction of the f32-MFMA cost.
+ *
+ * NQA_PREC_F32M ("mixed", DISTS pyramid entry points only: nqa_pack_vgg_weights, nqa_workspace_bytes,
+ * nqa_vgg_pyramid, nqa_dists_forward): stages 1..3 (conv layers 0..6) keep f16 NHWC activations and multiply them
+ * with weights held as f16 (hi, lo) pairs -- TWO MFMAs per product, the weights' 11-bit rounding removed -- and
+ * stages 4..5 (layers 7..12) run as NQA_PREC_F32S; the L2-pool after stage 3 turns the f16 tap into split16
+ * records.  Taps 1..3 are half, taps 4..5 float.  What is left of the 16-bit error is the activation rounding of the
+ * first seven layers, whose contribution to a DISTS score is the smallest of all (tools/cpu_prec_layers.py). */
+enum { NQA_PREC_F32 = 0, NQA_PREC_BF16 = 1, NQA_PREC_F16 = 2, NQA_PREC_F32S = 3, NQA_PREC_F32M = 4 };
+#define NQA_MIXED_STAGES 3 /* NQA_PREC_F32M: pyramid stages (1-based) run with f16 activations + two-term weights */
 
 enum {
   NQA_OK = 0,

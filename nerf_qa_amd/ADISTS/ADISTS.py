@@ -56,7 +56,9 @@ class ADISTS(torch.nn.Module):
         for k in range(len(self.chns)):
             self.windows.append(self.create_window(self.window_size, self.window_size / 3, self.chns[k]))
         self.precision = precision or os.environ.get("NQA_ADISTS_PRECISION", DEFAULT_PRECISION)
-        prec_id(self.precision)
+        if prec_id(self.precision) == 4:
+            raise ValueError("precision 'f32m' is a DISTS mode: A-DISTS needs float precision in every layer "
+                             "(see the module docstring); use 'f32s' (default), 'f32' or the opt-in 'f16'")
         self._packed = None
         self._packed_key = None
         self._ws = ops.Workspace()

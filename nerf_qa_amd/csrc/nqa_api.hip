@@ -58,11 +58,14 @@ TimedLaunch::~TimedLaunch() {
 }
 
 // ---- packed weight blob -------------------------------------------------------------
+// bytes per weight in the blob of `prec`: NQA_PREC_F32M holds f16 (hi, lo) pairs for layers 1..6 and f32s rows
+// (also hi + lo halves) for layers 7..12
+static size_t blob_weight_bytes(int prec) { return prec == NQA_PREC_F32M ? 4 : prec_elem_bytes(prec); }
 static size_t layer_bytes(int layer, int prec) {
   const ConvSpec &c = kConvs[layer];
   if (layer == 0) return align_up(27 * 64 * 4 + 64 * 4, 256) + 6144;
   // weights, then float bias[cout] followed by ONE float: 1 / (the layer's power-of-two weight scale)
-  return align_up((size_t)c.cin * c.cout * 9 * prec_elem_bytes(prec), 256) + align_up((size_t)c.cout * 4 + 4, 256);
+  return align_up((size_t)c.cin * c.cout * 9 * blob_weight_bytes(prec), 256) + align_up((size_t)c.cout * 4 + 4, 256);
 }
 size_t layer_offset(int layer, int prec) {
   size_t o = kZeroPage;
@@ -89,7 +92,7 @@ size_t layer0_m16_offset(int prec) { return regw_offset(kRegwLast + 1, prec); }
 size_t layer_bias_offset(int layer, int prec) {
   const ConvSpec &c = kConvs[layer];
   if (layer == 0) return layer_offset(0, prec) + 27 * 64 * 4;
-  return layer_offset(layer, prec) + align_up((size_t)c.cin * c.cout * 9 * prec_elem_bytes(prec), 256);
+  return layer_offset(layer, prec) + align_up((size_t)c.cin * c.cout * 9 * blob_weight_bytes(prec), 256);
 }
 
 static uint16_t f32_to_bf16(float f) {
@@ -162,6 +165,20 @@ size_t max_act_elems(int H, int W) {
   return m;
 }
 static size_t act_bytes(int n, int H, int W, int prec) {
+  if (prec == NQA_PREC_F32M) {  // the largest map in BYTES: stages differ in element size
+    static const int kStageC[5] = {64, 128, 256, 512, 512};
+    const PyrDims d = pyr_dims(H, W);
+    size_t m = 0;
+    for (int k = 0; k < 5; ++k) {
+      const size_t e = (size_t)d.h[k] * d.w[k] * kStageC[k] * prec_elem_bytes(stage_prec(prec, k));
+      m = e > m ? e : m;
+      if (k > 0) {  // stage k's input: stage k-1's pooled map in stage k's format
+        const size_t p = (size_t)d.h[k] * d.w[k] * kStageC[k - 1] * prec_elem_bytes(stage_prec(prec, k));
+        m = p > m ? p : m;
+      }
+    }
+    return align_up((size_t)n * m, 256);
+  }
   return align_up((size_t)n * max_act_elems(H, W) * prec_elem_bytes(prec), 256);
 }
 
@@ -177,6 +194,35 @@ static int run_stages(const float *x, const float *y, int nx, void *bufA, void *
   const PyrDims d = pyr_dims(H, W);
   void *cur = bufA;
   int rc;
+  if (prec == NQA_PREC_F32M) {
+    // mixed mode: conv1_1 exact in float -> half; layers 1..6 the f16 kernels on two-term weights; the pool behind
+    // stage 3 writes split16 records; layers 7..12 the f32s kernels.  on_tap sees the stage's own kernel precision.
+    if ((rc = conv1_1_blob(x, nx, H, W, packed, prec, NQA_PREC_F16, bufA, st))) return rc;
+    if (n > nx && (rc = conv1_1_blob(y, n - nx, H, W, packed, prec, NQA_PREC_F16,
+                                     static_cast<char *>(bufA) + (size_t)nx * H * W * 64 * 2, st)))
+      return rc;
+    for (int layer = 1; layer < NQA_NUM_CONVS; ++layer) {
+      const ConvSpec &cs = kConvs[layer];
+      const int k = cs.stage, kp = stage_prec(prec, k);
+      void *dst = (cs.last && taps) ? taps[k] : (cur == bufA ? bufB : bufA);
+      if ((rc = conv3x3_blob(cur, n, d.h[k], d.w[k], layer, packed, prec, kp, dst, st))) return rc;
+      cur = dst;
+      if (cs.last) {
+        void *pdst = k < 4 ? ((cur == bufA) ? bufB : bufA) : nullptr;
+        if ((rc = on_tap(k, cur, d.h[k], d.w[k], cs.cout, pdst)) < 0) return rc;
+        if (k < 4) {
+          if (rc == 0) {
+            const bool boundary = kp == NQA_PREC_F16 && stage_prec(prec, k + 1) == NQA_PREC_F32S;
+            rc = boundary ? l2pool_to_split16(cur, n, d.h[k], d.w[k], cs.cout, pdst, st)
+                          : l2pool(cur, n, d.h[k], d.w[k], cs.cout, kp, pdst, st);
+            if (rc) return rc;
+          }
+          cur = pdst;
+        }
+      }
+    }
+    return NQA_OK;
+  }
   const bool fused1 = prec_elem_bytes(prec) == 2;
   if (!fused1) {
     if ((rc = conv1_1(x, nx, H, W, packed, prec, bufA, st))) return rc;
@@ -209,13 +255,14 @@ static int run_stages(const float *x, const float *y, int nx, void *bufA, void *
 // `chan`: the widest H x W map the call addresses with 32-bit in-image byte offsets (the conv DMA
 // plan): 64 channels for the pyramid paths (H, W are stage-1 sizes; later stages have 1/4 of the
 // pixels per doubling of the channels), the layer's own input width for the single-operator calls.
-static bool bad_dims(const char *who, int n, int H, int W, int prec, int chan = 512) {
+static bool bad_dims(const char *who, int n, int H, int W, int prec, int chan = 512, bool pyramid = false) {
   if (n <= 0 || H <= 0 || W <= 0) {
     set_error("%s: non-positive size n=%d H=%d W=%d", who, n, H, W);
     return true;
   }
-  if (!prec_valid(prec)) {
-    set_error("%s: unknown prec %d", who, prec);
+  if (!(pyramid ? prec_valid_pyramid(prec) : prec_valid(prec))) {
+    set_error(prec == NQA_PREC_F32M ? "%s: NQA_PREC_F32M (%d) is a mode of the DISTS pyramid entry points only"
+                                    : "%s: unknown prec %d", who, prec);
     return true;
   }
   if (chan > 0 && (long)H * W * chan * (long)prec_elem_bytes(prec) >= (1L << 31)) {
@@ -239,13 +286,14 @@ static StatsPlan stats_plan(int B, const int *C, const int *HW, const int (*pool
   int coff = 0;
   for (int k = 0; k < nstage; ++k) {
     const bool nchw = !pooled || k == 0;
+    const int kp = k >= 1 ? stage_prec(prec, k - 1) : prec;  // tap k comes out of pyramid stage k-1 (0-based)
     int nblk;
     if (nchw)
       nblk = cdiv(HW[k], stats_nchw_ppb(HW[k]));
     else if (pooled[k][0])
-      nblk = pool_stats_tiles(pooled[k][0], pooled[k][1], C[k], prec, B, nullptr, nullptr);
+      nblk = pool_stats_tiles(pooled[k][0], pooled[k][1], C[k], kp, B, nullptr, nullptr);
     else
-      nblk = cdiv(HW[k], stats_units_per_block(HW[k], C[k], prec, B));
+      nblk = cdiv(HW[k], stats_units_per_block(HW[k], C[k], kp, B));
     p.d.part_off[k] = off;
     p.d.nblk[k] = nblk;
     p.d.hw[k] = HW[k];
@@ -306,8 +354,9 @@ int nqa_timing_collect(int launches[NQA_K_COUNT], double ms[NQA_K_COUNT]) {
 }
 
 size_t nqa_packed_weights_bytes(int prec) {
+  if (!prec_valid_pyramid(prec)) return 0;
   size_t n = layer_offset(NQA_NUM_CONVS, prec);
-  if (prec_valid(prec) && prec_elem_bytes(prec) == 2) n = layer0_m16_offset(prec) + kW1M16Bytes;
+  if (prec != NQA_PREC_F32M && prec_elem_bytes(prec) == 2) n = layer0_m16_offset(prec) + kW1M16Bytes;
   return n;
 }
 
@@ -317,7 +366,7 @@ int nqa_pack_vgg_weights(const float *const w_host[NQA_NUM_CONVS], const float *
     set_error("pack_vgg_weights: null pointer");
     return NQA_E_ARG;
   }
-  if (!prec_valid(prec)) {
+  if (!prec_valid_pyramid(prec)) {
     set_error("pack_vgg_weights: unknown prec %d", prec);
     return NQA_E_ARG;
   }
@@ -329,7 +378,7 @@ int nqa_pack_vgg_weights(const float *const w_host[NQA_NUM_CONVS], const float *
       for (int c = 0; c < 3; ++c)
         for (int t = 0; t < 9; ++t) w0[(t * 3 + c) * 64 + co] = w_host[0][(co * 3 + c) * 9 + t];
     memcpy(blob + layer_bias_offset(0, prec), b_host[0], 64 * 4);
-    if (prec_elem_bytes(prec) == 2) {  // MFMA A fragments for the fused stage-1 kernel
+    if (prec != NQA_PREC_F32M && prec_elem_bytes(prec) == 2) {  // MFMA A fragments for the fused stage-1 kernel
       uint16_t *wm = reinterpret_cast<uint16_t *>(blob + layer0_mfma_offset(prec));
       for (int ky = 0; ky < 3; ++ky)
         for (int co = 0; co < 64; ++co)
@@ -341,16 +390,52 @@ int nqa_pack_vgg_weights(const float *const w_host[NQA_NUM_CONVS], const float *
             }
     }
   }
-  const int cpc = prec_elem_bytes(prec) == 4 ? 4 : 8, kc = 4 * cpc;
   for (int l = 1; l < NQA_NUM_CONVS; ++l) {
     const ConvSpec &cs = kConvs[l];
+    // the kernel precision that reads this layer: NQA_PREC_F32M = f16 kernels (two-term weights) for layers 1..6,
+    // f32s kernels for the rest
+    const int lprec = stage_prec(prec, cs.stage), nterm = layer_terms(prec, l);
+    const int cpc = prec_elem_bytes(lprec) == 4 ? 4 : 8, kc = 4 * cpc;
     const int bn = 64, ncc = cs.cin / kc;
     char *dst = blob + layer_offset(l, prec);
     {  // 1 / weight scale behind the bias (1 in every mode but f32s)
       float one = 1.f;
       memcpy(blob + layer_bias_offset(l, prec) + (size_t)cs.cout * 4, &one, 4);
     }
-    if (prec == NQA_PREC_F32S) {
+    if (nterm == 2) {
+      // f16 (hi, lo) pairs of the weights times a power of two (as for f32s below: lo must be a NORMAL half), in
+      // the stage order of conv3x3_igemm_kernel<..., NTERM = 2>: per 64-channel sub-slab and 32-channel chunk,
+      // [ky][part: hi, lo][kx][64 rows][4 chunks of 8 halfs]; chunk swizzle as in the one-term 16-bit blob
+      float wmax = 0.f;
+      for (size_t i = 0; i < (size_t)cs.cout * cs.cin * 9; ++i) wmax = fmaxf(wmax, fabsf(w_host[l][i]));
+      int k = 0;
+      if (wmax > 0.f && isfinite(wmax)) {
+        k = (int)floor(log2(1024.0 / (double)wmax));
+        k = k < -8 ? -8 : (k > 24 ? 24 : k);
+      }
+      const float wscale = ldexpf(1.f, k), winv = ldexpf(1.f, -k);
+      memcpy(blob + layer_bias_offset(l, prec) + (size_t)cs.cout * 4, &winv, 4);
+      for (int ct = 0; ct < cs.cout / bn; ++ct)
+        for (int cc = 0; cc < ncc; ++cc)
+          for (int ky = 0; ky < 3; ++ky)
+            for (int part = 0; part < 2; ++part)
+              for (int kx = 0; kx < 3; ++kx)
+                for (int n = 0; n < bn; ++n)
+                  for (int pos = 0; pos < 4; ++pos) {
+                    const int c = pos ^ (l >= 2 ? ((n >> 2) & 1) * 2 : (n >> 2) & 3);
+                    uint16_t *row = reinterpret_cast<uint16_t *>(dst) +
+                                    ((((((((size_t)ct * ncc + cc) * 3 + ky) * 2 + part) * 3 + kx) * bn + n) * 4 + pos) * 8);
+                    for (int j = 0; j < 8; ++j) {
+                      const int cin = cc * 32 + c * 8 + j, cout = ct * bn + n;
+                      const float v = w_host[l][((size_t)cout * cs.cin + cin) * 9 + ky * 3 + kx] * wscale;
+                      const uint16_t hi = f32_to_f16(v);
+                      row[j] = part == 0 ? hi : f32_to_f16(v - f16_to_f32(hi));
+                    }
+                  }
+      memcpy(blob + layer_bias_offset(l, prec), b_host[l], (size_t)cs.cout * 4);
+      continue;
+    }
+    if (lprec == NQA_PREC_F32S) {
       // rows of 16 input channels as [hi 0-7 | hi 8-15 | lo 0-7 | lo 8-15] halves, lo = f16(w*s - hi).
       // s is a power of two per layer that puts the layer's largest |w| in [512, 1024): a VGG weight is
       // ~1e-2, whose residual after the f16 `hi` (~5e-6) is a SUBNORMAL half with an absolute quantum of 6e-8
@@ -396,15 +481,15 @@ int nqa_pack_vgg_weights(const float *const w_host[NQA_NUM_CONVS], const float *
               for (int j = 0; j < cpc; ++j) {
                 const int cin = cc * kc + c * cpc + j, cout = ct * bn + n;
                 const float v = w_host[l][((size_t)cout * cs.cin + cin) * 9 + t];
-                if (prec == NQA_PREC_F32)
+                if (lprec == NQA_PREC_F32)
                   reinterpret_cast<float *>(dst)[e0 + j] = v;
                 else
-                  reinterpret_cast<uint16_t *>(dst)[e0 + j] = prec == NQA_PREC_BF16 ? f32_to_bf16(v) : f32_to_f16(v);
+                  reinterpret_cast<uint16_t *>(dst)[e0 + j] = lprec == NQA_PREC_BF16 ? f32_to_bf16(v) : f32_to_f16(v);
               }
             }
     memcpy(blob + layer_bias_offset(l, prec), b_host[l], (size_t)cs.cout * 4);
   }
-  if (prec_elem_bytes(prec) == 2) {
+  if (prec != NQA_PREC_F32M && prec_elem_bytes(prec) == 2) {
     for (int l = kRegwFirst; l <= kRegwLast; ++l) {
       const ConvSpec &cs = kConvs[l];
       const int nks = cs.cin / 32 * 9;  // k-steps: chunk * 9 + tap
@@ -529,7 +614,7 @@ int nqa_vgg_pyramid(const float *x, int n, int H, int W, const void *packed, int
       set_error("vgg_pyramid: taps[%d] is null", k);
       return NQA_E_ARG;
     }
-  if (bad_dims("vgg_pyramid", n, H, W, prec, 64)) return NQA_E_ARG;
+  if (bad_dims("vgg_pyramid", n, H, W, prec, 64, true)) return NQA_E_ARG;
   const size_t ab = act_bytes(n, H, W, prec);
   if (ws_bytes < 2 * ab) {
     set_error("vgg_pyramid: workspace %zu < %zu bytes", ws_bytes, 2 * ab);
@@ -547,7 +632,7 @@ int nqa_dists_forward(const float *x, const float *y, int B, int H, int W, const
     set_error("dists_forward: null pointer");
     return NQA_E_ARG;
   }
-  if (bad_dims("dists_forward", B, H, W, prec, 64)) return NQA_E_ARG;
+  if (bad_dims("dists_forward", B, H, W, prec, 64, true)) return NQA_E_ARG;
   const int n = 2 * B;
   const size_t need = nqa_workspace_bytes(n, H, W, prec);
   if (ws_bytes < need) {
@@ -567,8 +652,11 @@ int nqa_dists_forward(const float *x, const float *y, int B, int H, int W, const
       x, y, B, bufA, bufB, n, H, W, packed, prec, nullptr,
       [&](int k, void *tap, int hk, int wk, int ck, void *pool_dst) {
         double *pk = part + p.d.part_off[k + 1];
-        if (!pool_dst) return stats_nhwc(tap, B, hk * wk, ck, prec, pk, st);
-        const int rc2 = pool_stats(tap, B, hk, wk, ck, prec, pool_dst, pk, st);
+        const int kp = stage_prec(prec, k);  // (mixed mode: half taps up to stage 3, float ones behind)
+        if (!pool_dst) return stats_nhwc(tap, B, hk * wk, ck, kp, pk, st);
+        const bool boundary = prec == NQA_PREC_F32M && kp == NQA_PREC_F16 && stage_prec(prec, k + 1) == NQA_PREC_F32S;
+        const int rc2 = boundary ? pool_stats_to_split16(tap, B, hk, wk, ck, pool_dst, pk, st)
+                                 : pool_stats(tap, B, hk, wk, ck, kp, pool_dst, pk, st);
         return rc2 ? rc2 : 1;
       },
       st);

@@ -31,8 +31,12 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
+// T: element type of the maps a kernel READS (and, normally, writes); TO: element type of what the pooling
+// kernels WRITE (differs from T only at the mixed mode's f16 -> split16 boundary, PrecF16X).
 struct PrecF32 {
   typedef float T;
+  typedef float TO;
+  static constexpr bool OUT_SPLIT16 = false;
   static constexpr int ID = NQA_PREC_F32;
   static constexpr int CPC = 4;   // channels per 16-byte chunk
   static constexpr int KC = 16;   // channels per 64-byte LDS row
@@ -62,6 +66,8 @@ struct PrecF32S : PrecF32 {
 };
 struct PrecBF16 {
   typedef __bf16 T;
+  typedef __bf16 TO;
+  static constexpr bool OUT_SPLIT16 = false;
   static constexpr int ID = NQA_PREC_BF16;
   static constexpr int CPC = 8;
   static constexpr int KC = 32;
@@ -75,6 +81,8 @@ struct PrecBF16 {
 };
 struct PrecF16 {
   typedef _Float16 T;
+  typedef _Float16 TO;
+  static constexpr bool OUT_SPLIT16 = false;
   static constexpr int ID = NQA_PREC_F16;
   static constexpr int CPC = 8;
   static constexpr int KC = 32;
@@ -85,6 +93,13 @@ struct PrecF16 {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0,
                                                   0);
   }
+};
+
+// NQA_PREC_F32M, the L2-pool behind its last two-term stage: half taps in, split16 records out (they feed an
+// f32s conv layer)
+struct PrecF16X : PrecF16 {
+  typedef float TO;  // 4 bytes per element
+  static constexpr bool OUT_SPLIT16 = true;
 };
 
 // split16 store of the 4 consecutive channels c..c+3 (c % 4 == 0) of the pixel record at `pixel`
@@ -111,10 +126,31 @@ __device__ static inline void store_group(typename P::T *pixel, int c, const flo
   }
 }
 
+// what the pooling kernels write: P's own format, or split16 records at the mixed mode's boundary
+template <typename P>
+__device__ static inline void store_pooled(typename P::TO *pixel, int c, const float (&v)[P::CPC]) {
+  if constexpr (P::OUT_SPLIT16 && sizeof(typename P::T) == 2) {
+    store_split4(reinterpret_cast<char *>(pixel), c, v[0], v[1], v[2], v[3]);
+    store_split4(reinterpret_cast<char *>(pixel), c + 4, v[4], v[5], v[6], v[7]);
+  } else {
+    store_group<P>(reinterpret_cast<typename P::T *>(pixel), c, v);
+  }
+}
+
+// (NQA_PREC_F32M is a pyramid-level mode: its stages run as F16 / F32S kernels, see stage_prec; the packed blob
+// holds 4 bytes per weight in it -- f16 hi + lo, or the f32s rows)
 __host__ __device__ static inline size_t prec_elem_bytes(int prec) {
   return prec == NQA_PREC_F32 || prec == NQA_PREC_F32S ? 4 : 2;
 }
-static inline bool prec_valid(int prec) { return prec >= NQA_PREC_F32 && prec <= NQA_PREC_F32S; }
+static inline bool prec_valid(int prec) { return prec >= NQA_PREC_F32 && prec <= NQA_PREC_F32S; }  // kernel-level modes
+static inline bool prec_valid_pyramid(int prec) { return prec_valid(prec) || prec == NQA_PREC_F32M; }
+// the kernel precision of pyramid stage `stage` (0-based) in mode `prec`
+static inline int stage_prec(int prec, int stage) {
+  if (prec != NQA_PREC_F32M) return prec;
+  return stage < NQA_MIXED_STAGES ? NQA_PREC_F16 : NQA_PREC_F32S;
+}
+// weight terms per product of conv layer `layer` in mode `prec` (2: f16 hi + lo against f16 activations)
+static inline int layer_terms(int prec, int layer);
 // the precision the kernels that READ tapped maps see: in f32s those are plain float
 static inline int storage_prec(int prec) { return prec == NQA_PREC_F32S ? NQA_PREC_F32 : prec; }
 
@@ -127,6 +163,9 @@ static const ConvSpec kConvs[NQA_NUM_CONVS] = {
     {3, 64, 0, 0},    {64, 64, 0, 1},   {64, 128, 1, 0},  {128, 128, 1, 1}, {128, 256, 2, 0},
     {256, 256, 2, 0}, {256, 256, 2, 1}, {256, 512, 3, 0}, {512, 512, 3, 0}, {512, 512, 3, 1},
     {512, 512, 4, 0}, {512, 512, 4, 0}, {512, 512, 4, 1}};
+static inline int layer_terms(int prec, int layer) {
+  return prec == NQA_PREC_F32M && kConvs[layer].stage < NQA_MIXED_STAGES ? 2 : 1;
+}
 static const int kChns[NQA_NUM_TAPS] = {3, 64, 128, 256, 512, 512};
 static const int kChnOff[NQA_NUM_TAPS] = {0, 3, 67, 195, 451, 963};
 
@@ -170,6 +209,15 @@ int conv1_1(const float *x, int n, int H, int W, const void *packed, int prec, v
 int conv1_fused(const float *x, const float *y, int B, int n, int H, int W, const void *packed, int prec, void *out,
                 hipStream_t st);
 int conv3x3(const void *in, int n, int H, int W, int layer, const void *packed, int prec, void *out, hipStream_t st);
+// one conv layer of a blob packed for `blob_prec` run by the kernels of `kprec` (mixed mode: F16 with two-term
+// weights for layers 1..6, F32S for the rest); out_float: an F32S layer leaves plain float (a tapped map)
+int conv3x3_blob(const void *in, int n, int H, int W, int layer, const void *packed, int blob_prec, int kprec,
+                 void *out, hipStream_t st);
+int conv1_1_blob(const float *x, int n, int H, int W, const void *packed, int blob_prec, int kprec, void *out,
+                 hipStream_t st);
+int l2pool_to_split16(const void *in_f16, int n, int H, int W, int C, void *out_split16, hipStream_t st);
+int pool_stats_to_split16(const void *feat_f16, int B, int H, int W, int C, void *pooled_split16, double *part,
+                          hipStream_t st);
 int l2pool(const void *in, int n, int H, int W, int C, int prec, void *out, hipStream_t st);
 int stats_units_per_block(int units, int C, int prec, int B);
 int stats_nchw_ppb(int HW);

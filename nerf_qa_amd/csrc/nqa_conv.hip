@@ -182,7 +182,11 @@ __host__ __device__ inline int lds_swz(int r) {
 
 // M16: 16-bit modes on v_mfma_f32_16x16x32 (the chip holds a higher clock on it than on 32x32x16
 // at equal cycles per FLOP); weights of those layers are packed with the matching swizzle.
-template <typename P, int WAVES_N, int WAVES_M, int WN_T, int WM_T, int TW, bool M16>
+// NTERM = 2 (f16 activations, NQA_PREC_F32M's layers 1..6): the weights come as f16 (hi, lo) pairs, packed as TWO
+// consecutive stages per kernel row -- [hi: 3 taps][lo: 3 taps] -- that contract the SAME activation rows into the
+// same accumulators; nothing but the stage index -> (chunk, kernel row) map changes, and the epilogue multiplies by the
+// layer's exact power-of-two 1/scale (the weights are packed times 2^k so that lo is a normal half).
+template <typename P, int WAVES_N, int WAVES_M, int WN_T, int WM_T, int TW, bool M16, int NTERM = 1>
 __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void conv3x3_igemm_kernel(
     const typename P::T *__restrict__ in, const char *__restrict__ wpk, const float *__restrict__ bias,
     typename P::T *__restrict__ out, int H, int W, int Cin, int Cout, int tiles_x, int out_split) {
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void conv3x3_igemm_kernel(
   const int x0 = bx * TW, y0 = by * G::TH;
   const int wn = wave % WAVES_N, wm = wave / WAVES_N;
   const int nCC = Cin / P::KC;
-  const int S = nCC * 3;
+  const int S = nCC * 3 * NTERM;
 
   // ---- LDS-DMA plan: halo tile.  Buffer loads with the image as the buffer: an out-of-image
   // halo pixel gets an out-of-range offset, so the DMA transfers nothing for it (or zeros);
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void conv3x3_igemm_kernel(
   const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<T *>(in + (size_t)n * H * W * Cin), 0, img_bytes, 0x00020000);
   // ---- LDS-DMA plan: weight rows (sub-slab j, item idx) ----
-  const unsigned sub_stride = (unsigned)nCC * 9u * 64u * 64u;  // bytes between 64-channel sub-slabs
+  const unsigned sub_stride = (unsigned)nCC * 9u * 64u * 64u * (unsigned)NTERM;  // bytes between 64-channel sub-slabs
   const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<char *>(wpk + (size_t)ct * G::NSUB * sub_stride), 0, G::NSUB * sub_stride, 0x00020000);
   unsigned w_goff[G::W_ROUNDS];
@@ -257,13 +261,13 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void conv3x3_igemm_kernel(
   // retired by hand: dma_wait() before the barrier that publishes a stage.
   auto issue = [&](int s) {
 #ifndef NQA_ABLATE_NO_DMA
-    const int cc = s / 3;
+    const int cc = s / (3 * NTERM);
     char *wdst = smem + 2 * G::A_BYTES + (s & 1) * G::W_BYTES + wave_base;
 #pragma unroll
     for (int r = 0; r < G::W_ROUNDS; ++r)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void_t *)(wdst + r * G::THREADS * 16), 16, w_goff[r],
                                                s * (G::SUB_STAGE_ITEMS * 16), 0, 0);
-    if (s - cc * 3 == 0) {
+    if (s - cc * (3 * NTERM) == 0) {
       char *adst = smem + (cc & 1) * G::A_BYTES + wave_base;
 #pragma unroll
       for (int r = 0; r < G::A_ROUNDS; ++r) {
@@ -329,7 +333,7 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void conv3x3_igemm_kernel(
 #endif
   issue(0);
   for (int s = 0; s < S; ++s) {
-    const int cc = s / 3, ky = s - cc * 3;
+    const int cc = s / (3 * NTERM), ky = (s - cc * (3 * NTERM)) / NTERM;
     NQA_STAMP(t0);
     dma_wait();       // this wave's DMA for stage s has landed
     NQA_STAMP(t1);
@@ -494,12 +498,12 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void conv3x3_igemm_kernel(
   const size_t rec = (size_t)Cout * sizeof(T);
   // one lane's piece: 4 consecutive channels (first = cl, block-local) of the pixel staged in `row`
   // f32s: the weights were packed times a power of two (nqa_pack_vgg_weights); 1/scale sits behind the bias
-  const float winv = P::SPLIT ? bias[Cout] : 1.f;
+  const float winv = (P::SPLIT || NTERM == 2) ? bias[Cout] : 1.f;
   auto stage_piece = [&](int row, int cl, float a0, float a1, float a2, float a3) {
     char *const rbase = smem + row * RB;
     const int sw = row & SWZ;
     const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bias + ct * G::BN + cl);
-    if constexpr (P::SPLIT) {  // exact: winv is a power of two
+    if constexpr (P::SPLIT || NTERM == 2) {  // exact: winv is a power of two
       a0 *= winv;
       a1 *= winv;
       a2 *= winv;
@@ -1784,23 +1788,24 @@ void set_conv_first_forms(int on) {
 }
 
 template <typename P>
-static int launch_conv1_1(const float *x, int n, int H, int W, const char *packed, void *out, hipStream_t st) {
-  const float *w = reinterpret_cast<const float *>(packed + layer_offset(0, P::ID));
-  const float *b = reinterpret_cast<const float *>(packed + layer_bias_offset(0, P::ID));
+static int launch_conv1_1(const float *x, int n, int H, int W, const char *packed, void *out, hipStream_t st,
+                          int blob_prec = P::ID) {
+  const float *w = reinterpret_cast<const float *>(packed + layer_offset(0, blob_prec));
+  const float *b = reinterpret_cast<const float *>(packed + layer_bias_offset(0, blob_prec));
   dim3 grid(cdiv(H * W, 256), n);
   TimedLaunch t(NQA_K_CONV1, st);
   conv1_1_kernel<P><<<grid, 256, 0, st>>>(x, w, b, reinterpret_cast<typename P::T *>(out), H, W);
   return check_launch("conv1_1");
 }
 
-template <typename P, int WAVES_N, int WAVES_M, int WN_T, int WM_T, int TW, bool M16 = (sizeof(typename P::T) == 2)>
+template <typename P, int WAVES_N, int WAVES_M, int WN_T, int WM_T, int TW, bool M16 = (sizeof(typename P::T) == 2), int NTERM = 1>
 static int launch_igemm(const void *in, int n, int H, int W, int cin, int cout, const char *wpk, const float *bias,
                         void *out, int out_split, hipStream_t st) {
   typedef ConvGeom<WAVES_N, WAVES_M, WN_T, WM_T, TW> G;
   static std::atomic<bool> attr_done_dev[64];  // the attribute is per device: a process may drive several
   std::atomic<bool> &attr_done = attr_done_dev[current_device() & 63];
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_igemm_kernel<P, WAVES_N, WAVES_M, WN_T, WM_T, TW, M16>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_igemm_kernel<P, WAVES_N, WAVES_M, WN_T, WM_T, TW, M16, NTERM>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES) != hipSuccess) {
       set_error("conv3x3_igemm: cannot raise the dynamic LDS limit to %d bytes", G::LDS_BYTES);
       return NQA_E_LAUNCH;
@@ -1810,7 +1815,7 @@ static int launch_igemm(const void *in, int n, int H, int W, int cin, int cout, 
   const int tiles_x = cdiv(W, TW), tiles_y = cdiv(H, G::TH);
   dim3 grid(tiles_x * tiles_y, n, cout / G::BN);
   TimedLaunch t(NQA_K_CONV, st);
-  conv3x3_igemm_kernel<P, WAVES_N, WAVES_M, WN_T, WM_T, TW, M16><<<grid, G::THREADS, G::LDS_BYTES, st>>>(
+  conv3x3_igemm_kernel<P, WAVES_N, WAVES_M, WN_T, WM_T, TW, M16, NTERM><<<grid, G::THREADS, G::LDS_BYTES, st>>>(
       reinterpret_cast<const typename P::T *>(in), wpk, bias, reinterpret_cast<typename P::T *>(out), H, W, cin, cout,
       tiles_x, out_split);
   return check_launch("conv3x3_igemm");
@@ -1880,11 +1885,31 @@ static int launch_regw128(const void *in, int n, int H, int W, int layer, const 
   return check_launch("conv3x3_regw128");
 }
 
+// two-term weights (f16 kernels on an NQA_PREC_F32M blob): the same tile choices on the NTERM = 2 instances; the
+// register-weights kernels hold one-term fragments only, so every layer takes the implicit GEMM here
 template <typename P>
-static int launch_conv(const void *in, int n, int H, int W, int layer, const char *packed, void *out, hipStream_t st) {
+static int launch_conv_2term(const void *in, int n, int H, int W, const ConvSpec &cs, const char *wpk,
+                             const float *bias, void *out, bool narrow, bool big, hipStream_t st) {
+  if constexpr (sizeof(typename P::T) == 2 && P::ID == NQA_PREC_F16) {
+#define NQA_GO2(WN, WM, TN, TM, M16)                                                                                \
+  return narrow ? launch_igemm<P, WN, WM, TN, TM, 16, M16, 2>(in, n, H, W, cs.cin, cs.cout, wpk, bias, out, 0, st) \
+                : launch_igemm<P, WN, WM, TN, TM, 32, M16, 2>(in, n, H, W, cs.cin, cs.cout, wpk, bias, out, 0, st)
+    if (cs.cout == 64) { NQA_GO2(1, 4, 2, 2, false); }
+    if (!big) { NQA_GO2(2, 2, 2, 2, true); }
+    NQA_GO2(2, 4, 4, 2, true);
+#undef NQA_GO2
+  }
+  set_error("conv3x3: two-term weights exist for the f16 kernels only");
+  return NQA_E_ARG;
+}
+
+template <typename P>
+static int launch_conv(const void *in, int n, int H, int W, int layer, const char *packed, void *out, hipStream_t st,
+                       int blob_prec = P::ID) {
   const ConvSpec &cs = kConvs[layer];
-  const char *wpk = packed + layer_offset(layer, P::ID);
-  const float *bias = reinterpret_cast<const float *>(packed + layer_bias_offset(layer, P::ID));
+  const char *wpk = packed + layer_offset(layer, blob_prec);
+  const float *bias = reinterpret_cast<const float *>(packed + layer_bias_offset(layer, blob_prec));
+  const int nterm = layer_terms(blob_prec, layer);
   const bool narrow = W <= 16;  // 32-wide tiles would be half empty
   const int out_split = P::SPLIT && !cs.last;  // f32s: tapped layers leave as float, the others as split16
   // 8-wave 256 ch x 256 px tiles run ~10 % faster per FLOP than 4-wave 128 x 128 tiles on layers
@@ -1901,6 +1926,7 @@ static int launch_conv(const void *in, int n, int H, int W, int layer, const cha
     const long blocks_big = (long)cdiv(W, 32) * cdiv(H, 8) * n * (cs.cout / 256);
     if (blocks_big < 192) big = false;
   }
+  if (nterm == 2) return launch_conv_2term<P>(in, n, H, W, cs, wpk, bias, out, narrow, big, st);
   // 8-wave 128 ch x 512 px tiles: the loop is bound by what a CU can take in per clock (weights
   // 3*BN*64 B + halo per stage), and for the same 64 K accumulators 128 x 512 moves 37.6 KB per
   // stage where 256 x 256 moves 56 KB and two 128 x 128 blocks move 58 KB.
@@ -1922,9 +1948,11 @@ static int launch_conv(const void *in, int n, int H, int W, int layer, const cha
   }
   if constexpr (sizeof(typename P::T) == 2) {
     // conv2_1: register-resident weights (first-form bit of nqa_set_conv_variant: the implicit GEMM, for A/B runs)
-    if (layer == 2 && !g_first_forms && W >= 16) return launch_regw<P>(in, n, H, W, layer, packed, out, st);
-    if ((layer == 3 || layer == 4) && !g_no_regw128 && !g_first_forms && W >= 16)
-      return launch_regw128<P>(in, n, H, W, layer, packed, out, st);
+    if (blob_prec == P::ID) {  // (their fragments live in the 16-bit blobs only)
+      if (layer == 2 && !g_first_forms && W >= 16) return launch_regw<P>(in, n, H, W, layer, packed, out, st);
+      if ((layer == 3 || layer == 4) && !g_no_regw128 && !g_first_forms && W >= 16)
+        return launch_regw128<P>(in, n, H, W, layer, packed, out, st);
+    }
   }
   if (!big) { NQA_GO(2, 2, 2, 2); }                             // 128 ch x 128 px, 4 waves
   NQA_GO(2, 4, 4, 2);                                           // 256 ch x 256 px, 8 waves
@@ -2066,6 +2094,25 @@ int conv1_1(const float *x, int n, int H, int W, const void *packed, int prec, v
     case NQA_PREC_F16: return launch_conv1_1<PrecF16>(x, n, H, W, p, out, st);
   }
   set_error("conv1_1: unknown prec %d", prec);
+  return NQA_E_ARG;
+}
+
+int conv3x3_blob(const void *in, int n, int H, int W, int layer, const void *packed, int blob_prec, int kprec,
+                 void *out, hipStream_t st) {
+  const char *p = static_cast<const char *>(packed);
+  if (blob_prec == NQA_PREC_F32M) {
+    if (kprec == NQA_PREC_F16) return launch_conv<PrecF16>(in, n, H, W, layer, p, out, st, blob_prec);
+    if (kprec == NQA_PREC_F32S) return launch_conv<PrecF32S>(in, n, H, W, layer, p, out, st, blob_prec);
+  }
+  set_error("conv3x3_blob: unsupported blob / kernel precision pair %d / %d", blob_prec, kprec);
+  return NQA_E_ARG;
+}
+
+int conv1_1_blob(const float *x, int n, int H, int W, const void *packed, int blob_prec, int kprec, void *out,
+                 hipStream_t st) {
+  const char *p = static_cast<const char *>(packed);
+  if (blob_prec == NQA_PREC_F32M && kprec == NQA_PREC_F16) return launch_conv1_1<PrecF16>(x, n, H, W, p, out, st, blob_prec);
+  set_error("conv1_1_blob: unsupported blob / kernel precision pair %d / %d", blob_prec, kprec);
   return NQA_E_ARG;
 }
 

@@ -18,7 +18,7 @@ namespace nqa {
 // ---------------------------------------------------------------------------------
 template <typename P>
 __global__ __launch_bounds__(256) void l2pool_kernel(const typename P::T *__restrict__ in,
-                                                     typename P::T *__restrict__ out, int H, int W, int C, int Ho,
+                                                     typename P::TO *__restrict__ out, int H, int W, int C, int Ho,
                                                      int Wo, long total) {
   typedef typename P::T T;
   typedef __attribute__((ext_vector_type(P::CPC))) T tvec;
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void l2pool_kernel(const typename P::T *__rest
   }
 #pragma unroll
   for (int e = 0; e < P::CPC; ++e) acc[e] = sqrtf(acc[e] + 1e-12f);
-  store_group<P>(out + (((size_t)n * Ho + oy) * Wo + ox) * C, g * P::CPC, acc);
+  store_pooled<P>(out + (((size_t)n * Ho + oy) * Wo + ox) * C, g * P::CPC, acc);
 }
 
 // ---------------------------------------------------------------------------------
@@ -132,9 +132,14 @@ __device__ inline void reduce_store(const ShiftedMoments<CPC> &m, double *red, i
 // (2oy..2oy+1, 2ox..2ox+1), each owned by exactly one output pixel) to the sums.
 // (three blocks per CU for the float instances, 128 VGPRs; the 16-bit instances need 176 with the row-reuse
 // registers and would spill 12 B/lane at three -- they run two blocks per CU, which measured the same at 1080p)
+#ifdef NQA_POOL_NT  // A/B build: the tap is read once by this pass -> non-temporal loads
+#define NQA_TAP_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define NQA_TAP_LOAD(p) (*(p))
+#endif
 template <typename P>
 __global__ __launch_bounds__(256, sizeof(typename P::T) == 2 ? 2 : 3) void pool_stats_kernel(const typename P::T *__restrict__ feat,
-                                                         typename P::T *__restrict__ pooled, int B, int H, int W,
+                                                         typename P::TO *__restrict__ pooled, int B, int H, int W,
                                                          int C, int Ho, int Wo, int TR, int TC, int tiles_x,
                                                          int nblk, double *__restrict__ part) {
   typedef typename P::T T;
@@ -159,8 +164,8 @@ __global__ __launch_bounds__(256, sizeof(typename P::T) == 2 ? 2 : 3) void pool_
   const int oy0 = by * TR, ox0 = bx * TC, tile_units = TR * TC;
   const T *fx = feat + (size_t)b * H * W * C + g * P::CPC;
   const T *fy = feat + (size_t)(B + b) * H * W * C + g * P::CPC;
-  T *ox_ = pooled + (size_t)b * HoWo * C;
-  T *oy_ = pooled + (size_t)(B + b) * HoWo * C;
+  typename P::TO *ox_ = pooled + (size_t)b * HoWo * C;
+  typename P::TO *oy_ = pooled + (size_t)(B + b) * HoWo * C;
   ShiftedMoments<P::CPC> m;
   m.init();
   if (pl < tile_units) {  // pivot = a sample near this thread's first pixel (a window centre, always in range)
@@ -199,8 +204,8 @@ __global__ __launch_bounds__(256, sizeof(typename P::T) == 2 ? 2 : 3) void pool_
           vx[t] = keepx[t];
           vy[t] = keepy[t];
         } else {
-          vx[t] = *reinterpret_cast<const tvec *>(fx + o);
-          vy[t] = *reinterpret_cast<const tvec *>(fy + o);
+          vx[t] = NQA_TAP_LOAD(reinterpret_cast<const tvec *>(fx + o));
+          vy[t] = NQA_TAP_LOAD(reinterpret_cast<const tvec *>(fy + o));
         }
       }
     } else {
@@ -262,8 +267,8 @@ __global__ __launch_bounds__(256, sizeof(typename P::T) == 2 ? 2 : 3) void pool_
       px[e] = sqrtf(qx[e >> 1][e & 1] + 1e-12f);
       py[e] = sqrtf(qy[e >> 1][e & 1] + 1e-12f);
     }
-    store_group<P>(ox_ + (size_t)u * C, g * P::CPC, px);
-    store_group<P>(oy_ + (size_t)u * C, g * P::CPC, py);
+    store_pooled<P>(ox_ + (size_t)u * C, g * P::CPC, px);
+    store_pooled<P>(oy_ + (size_t)u * C, g * P::CPC, py);
   }
   reduce_store<P::CPC>(m, red, tid, G, PL, C, part + ((size_t)b * nblk + blk) * C * 5);
 }
@@ -428,8 +433,11 @@ static int launch_l2pool(const void *in, int n, int H, int W, int C, void *out, 
   const long total = (long)n * Ho * Wo * (C / P::CPC);
   TimedLaunch t(NQA_K_POOL, st);
   l2pool_kernel<P><<<dim3((unsigned)((total + 255) / 256)), 256, 0, st>>>(
-      reinterpret_cast<const typename P::T *>(in), reinterpret_cast<typename P::T *>(out), H, W, C, Ho, Wo, total);
+      reinterpret_cast<const typename P::T *>(in), reinterpret_cast<typename P::TO *>(out), H, W, C, Ho, Wo, total);
   return check_launch("l2pool");
+}
+int l2pool_to_split16(const void *in_f16, int n, int H, int W, int C, void *out_split16, hipStream_t st) {
+  return launch_l2pool<PrecF16X>(in_f16, n, H, W, C, out_split16, st);
 }
 
 int l2pool(const void *in, int n, int H, int W, int C, int prec, void *out, hipStream_t st) {
@@ -517,9 +525,13 @@ static int launch_pool_stats(const void *feat, int B, int H, int W, int C, void 
   const int nblk = pool_stats_tiles(Ho, Wo, C, P::ID, B, &TR, &TC);
   TimedLaunch t(NQA_K_POOL, st);
   pool_stats_kernel<P><<<nblk * B, 256, 0, st>>>(reinterpret_cast<const typename P::T *>(feat),
-                                                 reinterpret_cast<typename P::T *>(pooled), B, H, W, C, Ho, Wo, TR, TC,
+                                                 reinterpret_cast<typename P::TO *>(pooled), B, H, W, C, Ho, Wo, TR, TC,
                                                  cdiv(Wo, TC), nblk, part);
   return check_launch("pool_stats");
+}
+int pool_stats_to_split16(const void *feat_f16, int B, int H, int W, int C, void *pooled_split16, double *part,
+                          hipStream_t st) {
+  return launch_pool_stats<PrecF16X>(feat_f16, B, H, W, C, pooled_split16, part, st);
 }
 
 // tap (2B images: x then y) -> pooled (2B images) + statistics partials of the B pairs

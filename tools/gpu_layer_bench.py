@@ -13,7 +13,7 @@ from nerf_qa_amd import ops, synth  # noqa: E402
 
 dev = torch.device("cuda:0")
 which = sys.argv[1] if len(sys.argv) > 1 else "256"
-H, W, N = (256, 256, 64) if which == "256" else (1080, 1920, 8)
+H, W, N = (256, 256, 64) if which == "256" else (1080, 1920, 16)
 prec = os.environ.get("NQA_TOOL_PREC", "f16")
 DT = {"f16": torch.float16, "bf16": torch.bfloat16}.get(prec, torch.float32)
 packed = ops.pack_vgg_weights(synth.vgg16_weights(1234), prec).to(dev)
@@ -40,6 +40,8 @@ for layer in range(1, 13):
     h, w = dims[ops.CONV_STAGE[layer]]
     cin, cout = ops.CONV_CIN[layer], ops.CONV_COUT[layer]
     a = (torch.rand(N, h, w, cin, device=dev) - 0.5).clamp_min(0).to(DT)
+    if prec == "f32s":
+        a = ops.split16_encode(a.contiguous())  # conv layers read split16 records in this mode
     if os.environ.get('NQA_TOOL_ZERO'):
         a.zero_()  # clock check: zero operands toggle nothing, so the chip holds its clock (DVFS)
     fl = 2 * 9 * cin * cout * h * w * N
