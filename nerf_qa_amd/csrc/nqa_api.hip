@@ -78,14 +78,18 @@ size_t layer0_mfma_offset(int prec) { return layer_offset(0, prec) + align_up(27
 // k-step = chunk * 9 + tap (chunk = 32 input channels), lane = (row l15, k-group c4): element j is
 // w[cout = 32*g + 16*i + l15][cin = 32*chunk + 8*c4 + j][tap].  conv3x3_regw_kernel loads its 2 x 18 fragments
 // (144 VGPRs) once per persistent block.  Appended behind the ordinary layers.
-size_t regw_bytes(int layer) { return (size_t)kConvs[layer].cout * kConvs[layer].cin * 9 * 2; }
+// (NQA_PREC_F32M: the same fragments for 16 channels per group, once as the f16 `hi` and once as the `lo` part of the
+// scaled weights: [cout/16][part][k-steps][64 lanes][8 halfs])
+size_t regw_bytes(int layer, int prec) {
+  return (size_t)kConvs[layer].cout * kConvs[layer].cin * 9 * 2 * (prec == NQA_PREC_F32M ? 2 : 1);
+}
 static const int kRegwFirst = 1, kRegwLast = 4;  // conv1_2, conv2_1 (Cin 64); conv2_2, conv3_1 (Cin 128)
 // conv1_1 as 16x16x32 MFMA A fragments for conv1_regw_kernel: [4 tiles of 16 channels][2 MFMAs][64 lanes][8 halfs];
 // MFMA m contracts kernel rows 2m and 2m+1: k = 16*(ky - 2m) + 4*kx + c (kx, c padded to 4; zero for ky = 3)
 static constexpr size_t kW1M16Bytes = 4 * 2 * 64 * 16;
 size_t regw_offset(int layer, int prec) {
   size_t o = layer_offset(NQA_NUM_CONVS, prec);
-  for (int l = kRegwFirst; l < layer; ++l) o += regw_bytes(l);
+  for (int l = kRegwFirst; l < layer; ++l) o += regw_bytes(l, prec);
   return o;
 }
 size_t layer0_m16_offset(int prec) { return regw_offset(kRegwLast + 1, prec); }
@@ -133,6 +137,19 @@ static float f16_to_f32(uint16_t hv) {
   else if (e == 31) v = m ? NAN : INFINITY;
   else v = ldexpf((float)(m | 1024), e - 25);
   return (hv & 0x8000) ? -v : v;
+}
+
+// power of two that puts a layer's largest |w| in [512, 1024): the f16 `lo` part of a scaled weight is then a normal
+// half (see the f32s packing below); the conv epilogues multiply by the exact inverse
+static int weight_scale_exp(const float *w, size_t count) {
+  float wmax = 0.f;
+  for (size_t i = 0; i < count; ++i) wmax = fmaxf(wmax, fabsf(w[i]));
+  int k = 0;
+  if (wmax > 0.f && isfinite(wmax)) {
+    k = (int)floor(log2(1024.0 / (double)wmax));
+    k = k < -8 ? -8 : (k > 24 ? 24 : k);
+  }
+  return k;
 }
 
 // ---- drivers ----------------------------------------------------------------------------
@@ -197,15 +214,22 @@ static int run_stages(const float *x, const float *y, int nx, void *bufA, void *
   if (prec == NQA_PREC_F32M) {
     // mixed mode: conv1_1 exact in float -> half; layers 1..6 the f16 kernels on two-term weights; the pool behind
     // stage 3 writes split16 records; layers 7..12 the f32s kernels.  on_tap sees the stage's own kernel precision.
-    if ((rc = conv1_1_blob(x, nx, H, W, packed, prec, NQA_PREC_F16, bufA, st))) return rc;
-    if (n > nx && (rc = conv1_1_blob(y, n - nx, H, W, packed, prec, NQA_PREC_F16,
-                                     static_cast<char *>(bufA) + (size_t)nx * H * W * 64 * 2, st)))
-      return rc;
+    const bool fused_m = W >= 16 && !mixed_stage1_unfused();
+    if (!fused_m) {  // conv1_1 exact in float -> half, then conv1_2 as a layer of its own
+      if ((rc = conv1_1_blob(x, nx, H, W, packed, prec, NQA_PREC_F16, bufA, st))) return rc;
+      if (n > nx && (rc = conv1_1_blob(y, n - nx, H, W, packed, prec, NQA_PREC_F16,
+                                       static_cast<char *>(bufA) + (size_t)nx * H * W * 64 * 2, st)))
+        return rc;
+    }
     for (int layer = 1; layer < NQA_NUM_CONVS; ++layer) {
       const ConvSpec &cs = kConvs[layer];
       const int k = cs.stage, kp = stage_prec(prec, k);
       void *dst = (cs.last && taps) ? taps[k] : (cur == bufA ? bufB : bufA);
-      if ((rc = conv3x3_blob(cur, n, d.h[k], d.w[k], layer, packed, prec, kp, dst, st))) return rc;
+      if (layer == 1 && fused_m) {
+        if ((rc = conv1_fused_blob(x, y, nx, n, H, W, packed, prec, dst, st))) return rc;
+      } else if ((rc = conv3x3_blob(cur, n, d.h[k], d.w[k], layer, packed, prec, kp, dst, st))) {
+        return rc;
+      }
       cur = dst;
       if (cs.last) {
         void *pdst = k < 4 ? ((cur == bufA) ? bufB : bufA) : nullptr;
@@ -356,7 +380,7 @@ int nqa_timing_collect(int launches[NQA_K_COUNT], double ms[NQA_K_COUNT]) {
 size_t nqa_packed_weights_bytes(int prec) {
   if (!prec_valid_pyramid(prec)) return 0;
   size_t n = layer_offset(NQA_NUM_CONVS, prec);
-  if (prec != NQA_PREC_F32M && prec_elem_bytes(prec) == 2) n = layer0_m16_offset(prec) + kW1M16Bytes;
+  if (prec == NQA_PREC_F32M || prec_elem_bytes(prec) == 2) n = layer0_m16_offset(prec) + kW1M16Bytes * (prec == NQA_PREC_F32M ? 2 : 1);
   return n;
 }
 
@@ -406,13 +430,7 @@ int nqa_pack_vgg_weights(const float *const w_host[NQA_NUM_CONVS], const float *
       // f16 (hi, lo) pairs of the weights times a power of two (as for f32s below: lo must be a NORMAL half), in
       // the stage order of conv3x3_igemm_kernel<..., NTERM = 2>: per 64-channel sub-slab and 32-channel chunk,
       // [ky][part: hi, lo][kx][64 rows][4 chunks of 8 halfs]; chunk swizzle as in the one-term 16-bit blob
-      float wmax = 0.f;
-      for (size_t i = 0; i < (size_t)cs.cout * cs.cin * 9; ++i) wmax = fmaxf(wmax, fabsf(w_host[l][i]));
-      int k = 0;
-      if (wmax > 0.f && isfinite(wmax)) {
-        k = (int)floor(log2(1024.0 / (double)wmax));
-        k = k < -8 ? -8 : (k > 24 ? 24 : k);
-      }
+      const int k = weight_scale_exp(w_host[l], (size_t)cs.cout * cs.cin * 9);
       const float wscale = ldexpf(1.f, k), winv = ldexpf(1.f, -k);
       memcpy(blob + layer_bias_offset(l, prec) + (size_t)cs.cout * 4, &winv, 4);
       for (int ct = 0; ct < cs.cout / bn; ++ct)
@@ -488,6 +506,42 @@ int nqa_pack_vgg_weights(const float *const w_host[NQA_NUM_CONVS], const float *
               }
             }
     memcpy(blob + layer_bias_offset(l, prec), b_host[l], (size_t)cs.cout * 4);
+  }
+  if (prec == NQA_PREC_F32M) {
+    // conv1_1 for conv1_regw_kernel<.., NTERM = 2>: [4 tiles of 16 channels][2 MFMAs][part: hi, lo][64 lanes][8 halfs] of
+    // the weights times a power of two; 1 / that scale in the first float of the 32x32-fragment area
+    const int k1 = weight_scale_exp(w_host[0], 64 * 27);
+    const float s1 = ldexpf(1.f, k1), inv1 = ldexpf(1.f, -k1);
+    memcpy(blob + layer0_mfma_offset(prec), &inv1, 4);
+    uint16_t *w1 = reinterpret_cast<uint16_t *>(blob + layer0_m16_offset(prec));
+    for (int i = 0; i < 4; ++i)
+      for (int m = 0; m < 2; ++m)
+        for (int part = 0; part < 2; ++part)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 8; ++j) {
+              const int k = 8 * (lane >> 4) + j, ky = 2 * m + (k >> 4), kx = (k >> 2) & 3, c = k & 3;
+              const int cout = 16 * i + (lane & 15);
+              const float v = (ky < 3 && kx < 3 && c < 3) ? w_host[0][(cout * 3 + c) * 9 + ky * 3 + kx] * s1 : 0.f;
+              const uint16_t hi = f32_to_f16(v);
+              w1[((((size_t)i * 2 + m) * 2 + part) * 64 + lane) * 8 + j] = part == 0 ? hi : f32_to_f16(v - f16_to_f32(hi));
+            }
+    // two-term register fragments of layers 1..4 (conv3x3_regw_kernel<.., NTERM = 2> and regw128)
+    for (int l = kRegwFirst; l <= kRegwLast; ++l) {
+      const ConvSpec &cs = kConvs[l];
+      const int nks = cs.cin / 32 * 9;
+      const float wscale = ldexpf(1.f, weight_scale_exp(w_host[l], (size_t)cs.cout * cs.cin * 9));  // (as the layer's rows)
+      uint16_t *dst = reinterpret_cast<uint16_t *>(blob + regw_offset(l, prec));
+      for (int g = 0; g < cs.cout / 16; ++g)
+        for (int part = 0; part < 2; ++part)
+          for (int ks = 0; ks < nks; ++ks)
+            for (int lane = 0; lane < 64; ++lane)
+              for (int j = 0; j < 8; ++j) {
+                const int cout = 16 * g + (lane & 15), cin = 32 * (ks / 9) + 8 * (lane >> 4) + j, t = ks % 9;
+                const float v = w_host[l][((size_t)cout * cs.cin + cin) * 9 + t] * wscale;
+                const uint16_t hi = f32_to_f16(v);
+                dst[((((size_t)g * 2 + part) * nks + ks) * 64 + lane) * 8 + j] = part == 0 ? hi : f32_to_f16(v - f16_to_f32(hi));
+              }
+    }
   }
   if (prec != NQA_PREC_F32M && prec_elem_bytes(prec) == 2) {
     for (int l = kRegwFirst; l <= kRegwLast; ++l) {

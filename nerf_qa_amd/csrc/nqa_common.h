@@ -215,6 +215,9 @@ int conv3x3_blob(const void *in, int n, int H, int W, int layer, const void *pac
                  void *out, hipStream_t st);
 int conv1_1_blob(const float *x, int n, int H, int W, const void *packed, int blob_prec, int kprec, void *out,
                  hipStream_t st);
+int conv1_fused_blob(const float *x, const float *y, int B, int n, int H, int W, const void *packed, int blob_prec,
+                     void *out, hipStream_t st);
+bool mixed_stage1_unfused();  // (A/B switch of nqa_set_conv_variant's first-forms bit)
 int l2pool_to_split16(const void *in_f16, int n, int H, int W, int C, void *out_split16, hipStream_t st);
 int pool_stats_to_split16(const void *feat_f16, int B, int H, int W, int C, void *pooled_split16, double *part,
                           hipStream_t st);

@@ -584,7 +584,11 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void conv3x3_igemm_kernel(
 //     DMA pieces per tile and the ring is retired with ONE counted vmcnt per tile (stores and DMA count
 //     together, in issue order).
 // Tiles are dealt XCD-aware: the workgroups that share an L2 walk a contiguous range of tiles.
-template <typename P, int NCG>
+// NTERM = 2 (NQA_PREC_F32M): a wave owns 16 output channels and its two fragment sets are the f16 (hi, lo) parts of
+// THEIR weights (packed times the layer's power-of-two scale); both parts contract the same pixel fragments into
+// separate accumulators that are added, descaled and biased in the epilogue.  Same registers, same MFMAs and LDS
+// reads per tile as the one-term form; the block covers its COUT channels with twice the channel groups.
+template <typename P, int NCG, int NTERM = 1>
 __global__ __launch_bounds__(512) void conv3x3_regw_kernel(const typename P::T *__restrict__ in,
                                                            const char *__restrict__ wreg,
                                                            const float *__restrict__ bias,
@@ -593,18 +597,19 @@ __global__ __launch_bounds__(512) void conv3x3_regw_kernel(const typename P::T *
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef typename P::T T;
   constexpr int COUT = 32 * NCG, TH = 8, TW = 32, HWD = TW + 2, NQ = (TH + 2) * HWD;  // 340 halo pixels
+  constexpr int CW = 32 / NTERM, NG = COUT / CW;   // channels per wave, channel groups per block
   constexpr int CH_ITEMS = 1536, CH_BYTES = CH_ITEMS * 16, SLOT = 2 * CH_BYTES;       // 3 DMA rounds per chunk
   constexpr int NPIECE = 6;                        // DMA pieces per wave and tile
-  constexpr int RW = NCG;                          // tile rows per wave (8 rows over 8/NCG pixel parts)
+  constexpr int RW = NG;                           // tile rows per wave (8 rows over 8/NG pixel parts)
   constexpr int GPP = 2;                           // 16-pixel groups per pass (one 32-pixel tile row)
   constexpr int NPASS = 2 * RW / GPP;              // passes per wave and tile
-  constexpr int NSTORE = 2 * GPP * NPASS;          // buffer stores per wave and tile
-  static_assert(NCG == 2 || NCG == 4, "64 or 128 output channels");
+  constexpr int NSTORE = (2 / NTERM) * GPP * NPASS;  // buffer stores per wave and tile
+  static_assert((NCG == 2 || NCG == 4) && (NTERM == 1 || NTERM == 2) && NG <= 8, "64 or 128 output channels");
   extern __shared__ __attribute__((aligned(16))) char smem[];  // three halo slots
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, c4 = lane >> 4;
-  const int cg = wave % NCG, ph = wave / NCG;
+  const int cg = wave % NG, ph = wave / NG;
 
   // ---- this block's tiles: XCD x owns tiles [T*x/8, T*(x+1)/8), dealt round-robin to its blocks ----
   const int nblk = gridDim.x, nx = nblk < 8 ? nblk : 8;  // (a grid of fewer than 8 blocks has fewer classes)
@@ -632,7 +637,8 @@ __global__ __launch_bounds__(512) void conv3x3_regw_kernel(const typename P::T *
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) bia[i][e] = bias[cg * 32 + i * 16 + 4 * c4 + e];
+    for (int e = 0; e < 4; ++e) bia[i][e] = bias[NTERM == 2 ? cg * 16 + 4 * c4 + e : cg * 32 + i * 16 + 4 * c4 + e];
+  const float winv = NTERM == 2 ? bias[COUT] : 1.f;  // 1 / the two-term weights' power-of-two scale
 
   // ---- halo DMA plan: item j (16 B) of a chunk = quarter (j&3)^swz(q) of halo pixel q = j>>2; rounds r and r+3
   // are the two chunks of the same (pixel, quarter) ----
@@ -731,15 +737,23 @@ __global__ __launch_bounds__(512) void conv3x3_regw_kernel(const typename P::T *
       for (int g = 0; g < GPP; ++g) {
         const int gy = y0 + ph * RW + pass, gx = x0 + g * 16 + l15;
         const bool inside = gy < H && gx < W;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          typedef __attribute__((ext_vector_type(4))) T t4;
+        typedef __attribute__((ext_vector_type(4))) T t4;
+        if constexpr (NTERM == 2) {
           t4 v;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = P::from_f(fmaxf(acc[i][g][e] + bia[i][e], 0.f));
-          const unsigned off =
-              inside ? (unsigned)(((gy * W + gx) * COUT + cg * 32 + i * 16 + 4 * c4) * (int)sizeof(T)) : kOOB;
+          for (int e = 0; e < 4; ++e) v[e] = P::from_f(fmaxf((acc[0][g][e] + acc[1][g][e]) * winv + bia[0][e], 0.f));
+          const unsigned off = inside ? (unsigned)(((gy * W + gx) * COUT + cg * 16 + 4 * c4) * (int)sizeof(T)) : kOOB;
           __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), orsrc, off, 0, 0);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            t4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = P::from_f(fmaxf(acc[i][g][e] + bia[i][e], 0.f));
+            const unsigned off =
+                inside ? (unsigned)(((gy * W + gx) * COUT + cg * 32 + i * 16 + 4 * c4) * (int)sizeof(T)) : kOOB;
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), orsrc, off, 0, 0);
+          }
         }
       }
     }
@@ -759,7 +773,9 @@ __global__ __launch_bounds__(512) void conv3x3_regw_kernel(const typename P::T *
 // ahead; one barrier and one counted vmcnt per tile as in conv3x3_regw_kernel.  Every pixel fragment is read by
 // all four waves (0.5 LDS reads per MFMA again); a tap address serves its four chunks through immediate offsets.
 // Layers with 256 output channels run two such blocks per pixel tile (adjacent tile ids -> the halo hits L2).
-template <typename P, int PF>
+// NTERM = 2 (NQA_PREC_F32M): a wave's two fragment sets are the (hi, lo) parts of 16 channels' weights, a block covers
+// 64 output channels (Cout/64 blocks per pixel tile); see conv3x3_regw_kernel.
+template <typename P, int PF, int NTERM = 1>
 __global__ __launch_bounds__(256, 1) void conv3x3_regw128_kernel(const typename P::T *__restrict__ in,
                                                                 const char *__restrict__ wreg,
                                                                 const float *__restrict__ bias,
@@ -769,12 +785,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_regw128_kernel(const typename 
   typedef typename P::T T;
   constexpr int CIN = 128, NCC = 4, NKS = NCC * 9, TH = 4, TW = 32, HWD = TW + 2, NQ = (TH + 2) * HWD;  // 204
   constexpr int CH_ITEMS = 1024, CH_BYTES = CH_ITEMS * 16, SLOT = NCC * CH_BYTES;  // 4 DMA rounds of 256 per chunk
-  constexpr int GPP = 2, NPASS = TH, NSTORE = 2 * GPP * NPASS;  // (16 DMA pieces and 16 stores per wave and tile)
+  constexpr int GPP = 2, NPASS = TH, NSTORE = (2 / NTERM) * GPP * NPASS;  // (16 DMA pieces and 16 | 8 stores per wave and tile)
+  constexpr int BC = 128 / NTERM;  // output channels per block
   extern __shared__ __attribute__((aligned(16))) char smem[];  // two halo slots
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // = channel group of the block's 128 channels
   const int l15 = lane & 15, c4 = lane >> 4;
-  const int nct = Cout / 128;
+  const int nct = Cout / BC;
 
   const int nblk = gridDim.x, nx = nblk < 8 ? nblk : 8;
   const int xcd = blockIdx.x % nx, jb = blockIdx.x / nx;
@@ -808,9 +825,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_regw128_kernel(const typename 
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) bia[i][e] = bias[g * 32 + i * 16 + 4 * c4 + e];
+      for (int e = 0; e < 4; ++e) bia[i][e] = bias[NTERM == 2 ? g * 16 + 4 * c4 + e : g * 32 + i * 16 + 4 * c4 + e];
     cur_ct = ct;
   };
+  const float winv = NTERM == 2 ? bias[Cout] : 1.f;
 
   // ---- halo DMA plan: 4 rounds of 256 items per chunk; item j = quarter (j&3)^swz(q) of halo pixel q = j>>2 ----
   int p_hy[4], p_hx[4], p_c[4];
@@ -905,15 +923,24 @@ __global__ __launch_bounds__(256, 1) void conv3x3_regw128_kernel(const typename 
       for (int g = 0; g < GPP; ++g) {
         const int gy = y0 + pass, gx = x0 + g * 16 + l15;
         const bool inside = gy < H && gx < W;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          typedef __attribute__((ext_vector_type(4))) T t4;
+        typedef __attribute__((ext_vector_type(4))) T t4;
+        if constexpr (NTERM == 2) {
           t4 v;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = P::from_f(fmaxf(acc[i][g][e] + bia[i][e], 0.f));
+          for (int e = 0; e < 4; ++e) v[e] = P::from_f(fmaxf((acc[0][g][e] + acc[1][g][e]) * winv + bia[0][e], 0.f));
           const unsigned off =
-              inside ? (unsigned)(((gy * W + gx) * Cout + ct * 128 + wave * 32 + i * 16 + 4 * c4) * (int)sizeof(T)) : kOOB;
+              inside ? (unsigned)(((gy * W + gx) * Cout + ct * 64 + wave * 16 + 4 * c4) * (int)sizeof(T)) : kOOB;
           __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), orsrc, off, 0, 0);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            t4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = P::from_f(fmaxf(acc[i][g][e] + bia[i][e], 0.f));
+            const unsigned off =
+                inside ? (unsigned)(((gy * W + gx) * Cout + ct * 128 + wave * 32 + i * 16 + 4 * c4) * (int)sizeof(T)) : kOOB;
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), orsrc, off, 0, 0);
+          }
         }
       }
     }
@@ -939,31 +966,37 @@ __global__ __launch_bounds__(256, 1) void conv3x3_regw128_kernel(const typename 
 // Two halo images alternate; two barriers per tile (patch visible, halo visible).  conv1_1 is 6 % of the FLOPs
 // and costs the waves ~15 % of a tile here (it is not overlapped with conv1_2 of another wave group as in
 // conv1_fused_kernel below), against conv1_2 running at 0.5 LDS reads per MFMA instead of 1.5.
-template <typename P>
+// NTERM = 2 (NQA_PREC_F32M): both convolutions on two-term weights.  conv1_2 as conv3x3_regw_kernel<.., NTERM = 2> (a
+// wave = 16 output channels x 4 tile rows, fragment sets = the hi / lo parts); conv1_1's fragments come as (hi, lo) pairs
+// too (twice the MFMAs of a phase that is 6 % of the FLOPs), its accumulator starts at bias x scale and is descaled
+// before the ReLU.  *w1inv_p = 1 / conv1_1's power-of-two weight scale (not read in the one-term form).
+template <typename P, int NTERM = 1>
 __global__ __launch_bounds__(512) void conv1_regw_kernel(const float *__restrict__ x, const float *__restrict__ y, int B,
                                                          const char *__restrict__ w1m, const float *__restrict__ bias1,
                                                          const char *__restrict__ wreg, const float *__restrict__ bias2,
                                                          typename P::T *__restrict__ out, int H, int W, int tiles_x,
-                                                         int tiles_y, int total_tiles) {
+                                                         int tiles_y, int total_tiles, const float *__restrict__ w1inv_p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef typename P::T T;
   typedef __attribute__((ext_vector_type(4))) T t4;
-  constexpr int NCG = 2, COUT = 64, TH = 8, TW = 32, HWD = TW + 2, NQ = (TH + 2) * HWD;  // 340 halo pixels
+  constexpr int COUT = 64, TH = 8, TW = 32, HWD = TW + 2, NQ = (TH + 2) * HWD;  // 340 halo pixels
   // halo image [chunk][pixel][96 B]: a pixel's 32 channels (64 B) + 32 B of padding.  With a 96-byte pitch a
   // ds_read_b128 of 16 consecutive pixels at one 16-byte quarter is bank-conflict-free WITHOUT an XOR swizzle (the
   // image is written by ds_write here, not by 1-KB LDS-DMA pieces, so the pitch is free), and then a tap is a
   // compile-time byte offset from one per-group base register: no address arithmetic in the k loop.
   constexpr int PITCH = 96, CH_BYTES = 352 * PITCH, SLOT = 2 * CH_BYTES;
   constexpr int RAWP = 40, RAW_ROWS = 13, RAW_BYTES = RAW_ROWS * RAWP * 8;  // (+1 row read, with zero weights, by MFMA 1)
-  constexpr int RAW_OFF = 2 * SLOT, W1_OFF = RAW_OFF + 2 * RAW_BYTES, B1_OFF = W1_OFF + 4 * 2 * 64 * 16;  // two raw patches
-  constexpr int RW = NCG, GPP = 2, NPASS = 2 * RW / GPP;
+  constexpr int RAW_OFF = 2 * SLOT, W1_OFF = RAW_OFF + 2 * RAW_BYTES, B1_OFF = W1_OFF + NTERM * 4 * 2 * 64 * 16;  // two raw patches
+  constexpr int CW = 32 / NTERM, NG = COUT / CW;  // channels per wave, channel groups (2 of 32 | 4 of 16)
+  constexpr int RW = NG, GPP = 2, NPASS = 2 * RW / GPP;
   constexpr int NGRP = (NQ + 15) / 16;  // 22 groups of 16 halo pixels
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [halo 0][halo 1][raw 0][raw 1][conv1_1 fragments][bias1]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, c4 = lane >> 4;
-  const int cg = wave % NCG, ph = wave / NCG;
+  const int cg = wave % NG, ph = wave / NG;
   const int HW = H * W;
+  const float w1inv = NTERM == 2 ? w1inv_p[0] : 1.f;
 
   const int nblk = gridDim.x, nx = nblk < 8 ? nblk : 8;
   const int xcd = blockIdx.x % nx, jb = blockIdx.x / nx;
@@ -990,9 +1023,12 @@ __global__ __launch_bounds__(512) void conv1_regw_kernel(const float *__restrict
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) bia[i][e] = bias2[cg * 32 + i * 16 + 4 * c4 + e];
-  reinterpret_cast<u32x4 *>(smem + W1_OFF)[tid] = reinterpret_cast<const u32x4 *>(w1m)[tid];  // 8 KB = 512 x 16 B
-  if (tid < 64) reinterpret_cast<float *>(smem + B1_OFF)[tid] = bias1[tid];
+    for (int e = 0; e < 4; ++e) bia[i][e] = bias2[NTERM == 2 ? cg * 16 + 4 * c4 + e : cg * 32 + i * 16 + 4 * c4 + e];
+  const float winv2 = NTERM == 2 ? bias2[COUT] : 1.f;
+#pragma unroll
+  for (int r = 0; r < NTERM; ++r)  // 8 KB = 512 x 16 B per term
+    reinterpret_cast<u32x4 *>(smem + W1_OFF)[r * 512 + tid] = reinterpret_cast<const u32x4 *>(w1m)[r * 512 + tid];
+  if (tid < 64) reinterpret_cast<float *>(smem + B1_OFF)[tid] = NTERM == 2 ? bias1[tid] / w1inv : bias1[tid];  // (exact)
   for (int i = tid; i < 2 * RAW_BYTES / 8; i += 512) reinterpret_cast<u32x2 *>(smem + RAW_OFF)[i] = (u32x2){0u, 0u};
 
   // ---- raw patch: thread t < 432 owns pixel (t / 36, t % 36) of the 12 x 36 patch ----
@@ -1059,18 +1095,21 @@ __global__ __launch_bounds__(512) void conv1_regw_kernel(const float *__restrict
         bfr[u] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const u32x4 wfr = *reinterpret_cast<const u32x4 *>(smem + W1_OFF + ((i * 2 + m) * 64 + lane) * 16);
+      for (int part = 0; part < NTERM; ++part)
 #pragma unroll
-        for (int u = 0; u < NU; ++u) {
-          if (wave + 8 * u < NGRP) {  // (wave-uniform)
-            if constexpr (P::ID == NQA_PREC_BF16)
-              a1[u][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wfr), __builtin_bit_cast(bf16x8, bfr[u]), a1[u][i], 0, 0, 0);
-            else
-              a1[u][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wfr), __builtin_bit_cast(f16x8, bfr[u]), a1[u][i], 0, 0, 0);
+        for (int i = 0; i < 4; ++i) {
+          const u32x4 wfr =
+              *reinterpret_cast<const u32x4 *>(smem + W1_OFF + ((((i * 2 + m) * NTERM + part) * 64 + lane) * 16));
+#pragma unroll
+          for (int u = 0; u < NU; ++u) {
+            if (wave + 8 * u < NGRP) {  // (wave-uniform)
+              if constexpr (P::ID == NQA_PREC_BF16)
+                a1[u][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wfr), __builtin_bit_cast(bf16x8, bfr[u]), a1[u][i], 0, 0, 0);
+              else
+                a1[u][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wfr), __builtin_bit_cast(f16x8, bfr[u]), a1[u][i], 0, 0, 0);
+            }
           }
         }
-      }
     }
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
@@ -1082,7 +1121,7 @@ __global__ __launch_bounds__(512) void conv1_regw_kernel(const float *__restrict
         for (int i = 0; i < 4; ++i) {  // channels 16*i + 4*c4 .. +3: chunk i>>1, quarter 2*(i&1) + (c4>>1), half (c4&1)
           t4 v;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = P::from_f(fmaxf(a1[u][i][e], 0.f));
+          for (int e = 0; e < 4; ++e) v[e] = P::from_f(fmaxf(NTERM == 2 ? a1[u][i][e] * w1inv : a1[u][i][e], 0.f));
           if (!interior && !inside) v = (t4){P::from_f(0.f), P::from_f(0.f), P::from_f(0.f), P::from_f(0.f)};
           *reinterpret_cast<t4 *>(slot + (i >> 1) * CH_BYTES + q * PITCH + ((2 * (i & 1) + (c4 >> 1)) << 4) +
                                   (c4 & 1) * 8) = v;
@@ -1155,14 +1194,22 @@ __global__ __launch_bounds__(512) void conv1_regw_kernel(const float *__restrict
       for (int g = 0; g < GPP; ++g) {
         const int gy = y0 + ph * RW + pass, gx = x0 + g * 16 + l15;
         const bool inside = gy < H && gx < W;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        if constexpr (NTERM == 2) {
           t4 v;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = P::from_f(fmaxf(acc[i][g][e] + bia[i][e], 0.f));
-          const unsigned off =
-              inside ? (unsigned)(((gy * W + gx) * COUT + cg * 32 + i * 16 + 4 * c4) * (int)sizeof(T)) : kOOB;
+          for (int e = 0; e < 4; ++e) v[e] = P::from_f(fmaxf((acc[0][g][e] + acc[1][g][e]) * winv2 + bia[0][e], 0.f));
+          const unsigned off = inside ? (unsigned)(((gy * W + gx) * COUT + cg * 16 + 4 * c4) * (int)sizeof(T)) : kOOB;
           __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), orsrc, off, 0, 0);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            t4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = P::from_f(fmaxf(acc[i][g][e] + bia[i][e], 0.f));
+            const unsigned off =
+                inside ? (unsigned)(((gy * W + gx) * COUT + cg * 32 + i * 16 + 4 * c4) * (int)sizeof(T)) : kOOB;
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), orsrc, off, 0, 0);
+          }
         }
       }
 #pragma unroll
@@ -1782,6 +1829,7 @@ void set_conv_variant(int v) {
   g_conv_variant = v & 3;
   g_stage1_variant = (v >> 2) & 1;
 }
+bool mixed_stage1_unfused() { return g_first_forms != 0; }
 void set_conv_first_forms(int on) {
   g_first_forms = on & 1;
   g_no_regw128 = (on >> 1) & 1;
@@ -1824,14 +1872,16 @@ static int launch_igemm(const void *in, int n, int H, int W, int cin, int cout, 
 // compute units of the current device (cached per device: a process may drive several)
 static int num_cus();
 
-// conv2_1 (64 -> 128) with register-resident weights, 16-bit modes; persistent, one 8-wave block per CU
-template <typename P>
-static int launch_regw(const void *in, int n, int H, int W, int layer, const char *packed, void *out, hipStream_t st) {
+// conv2_1 (64 -> 128; NCG = 4) and, on two-term weights, conv1_2 (64 -> 64; NCG = 2) with register-resident
+// weights, 16-bit kernels; persistent, one 8-wave block per CU
+template <typename P, int NCG = 4, int NTERM = 1>
+static int launch_regw(const void *in, int n, int H, int W, int layer, const char *packed, void *out, hipStream_t st,
+                       int blob_prec = P::ID) {
   constexpr int LDS = 3 * 2 * 1536 * 16;
   static std::atomic<bool> attr_done_dev[64];
   std::atomic<bool> &attr_done = attr_done_dev[current_device() & 63];
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_regw_kernel<P, 4>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_regw_kernel<P, NCG, NTERM>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
       set_error("conv3x3_regw: cannot raise the dynamic LDS limit to %d bytes", LDS);
       return NQA_E_LAUNCH;
@@ -1845,22 +1895,24 @@ static int launch_regw(const void *in, int n, int H, int W, int layer, const cha
   }
   const int tiles_x = cdiv(W, 32), tiles_y = cdiv(H, 8), total = n * tiles_x * tiles_y;
   const int grid = total < cus ? total : cus;
-  const float *bias = reinterpret_cast<const float *>(packed + layer_bias_offset(layer, P::ID));
+  const float *bias = reinterpret_cast<const float *>(packed + layer_bias_offset(layer, blob_prec));
   TimedLaunch t(NQA_K_CONV, st);
-  conv3x3_regw_kernel<P, 4><<<grid, 512, LDS, st>>>(reinterpret_cast<const typename P::T *>(in),
-                                                    packed + regw_offset(layer, P::ID), bias,
-                                                    reinterpret_cast<typename P::T *>(out), H, W, tiles_x, tiles_y, total);
+  conv3x3_regw_kernel<P, NCG, NTERM><<<grid, 512, LDS, st>>>(reinterpret_cast<const typename P::T *>(in),
+                                                             packed + regw_offset(layer, blob_prec), bias,
+                                                             reinterpret_cast<typename P::T *>(out), H, W, tiles_x,
+                                                             tiles_y, total);
   return check_launch("conv3x3_regw");
 }
 
 // conv2_2 / conv3_1 (Cin 128) with register-resident weights, 16-bit modes; persistent, one 4-wave block per CU
-template <typename P>
-static int launch_regw128(const void *in, int n, int H, int W, int layer, const char *packed, void *out, hipStream_t st) {
+template <typename P, int NTERM = 1>
+static int launch_regw128(const void *in, int n, int H, int W, int layer, const char *packed, void *out, hipStream_t st,
+                          int blob_prec = P::ID) {
   constexpr int LDS = 2 * 4 * 1024 * 16, PF = 3;  // fragments three k-steps ahead (2: -6 %, 4: equal)
   static std::atomic<bool> attr_done_dev[64];
   std::atomic<bool> &attr_done = attr_done_dev[current_device() & 63];
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_regw128_kernel<P, PF>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_regw128_kernel<P, PF, NTERM>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
       set_error("conv3x3_regw128: cannot raise the dynamic LDS limit to %d bytes", LDS);
       return NQA_E_LAUNCH;
@@ -1872,25 +1924,33 @@ static int launch_regw128(const void *in, int n, int H, int W, int layer, const 
     set_error("conv3x3_regw128: cannot query the device");
     return NQA_E_LAUNCH;
   }
-  const int cout = kConvs[layer].cout;
-  const int tiles_x = cdiv(W, 32), tiles_y = cdiv(H, 4), total = n * tiles_x * tiles_y * (cout / 128);
+  const int cout = kConvs[layer].cout, nct = cout / (128 / NTERM);  // channel tiles (blocks) per pixel tile
+  const int tiles_x = cdiv(W, 32), tiles_y = cdiv(H, 4), total = n * tiles_x * tiles_y * nct;
   int grid = total < cus ? total : cus;
-  if (cout == 256 && grid > 8 && ((grid + 7) / 8) % 2) grid -= 8;  // even stride per XCD class: a block keeps its channel tile
-  const float *bias = reinterpret_cast<const float *>(packed + layer_bias_offset(layer, P::ID));
+  // a stride per XCD class that is a multiple of the channel tiles: a block then keeps its channel tile (its weights)
+  while (nct > 1 && grid > 8 * nct && ((grid + 7) / 8) % nct) grid -= 8;
+  const float *bias = reinterpret_cast<const float *>(packed + layer_bias_offset(layer, blob_prec));
   TimedLaunch t(NQA_K_CONV, st);
-  conv3x3_regw128_kernel<P, PF><<<grid, 256, LDS, st>>>(reinterpret_cast<const typename P::T *>(in),
-                                                        packed + regw_offset(layer, P::ID), bias,
-                                                        reinterpret_cast<typename P::T *>(out), H, W, cout, tiles_x,
-                                                        tiles_y, total);
+  conv3x3_regw128_kernel<P, PF, NTERM><<<grid, 256, LDS, st>>>(reinterpret_cast<const typename P::T *>(in),
+                                                               packed + regw_offset(layer, blob_prec), bias,
+                                                               reinterpret_cast<typename P::T *>(out), H, W, cout,
+                                                               tiles_x, tiles_y, total);
   return check_launch("conv3x3_regw128");
 }
 
 // two-term weights (f16 kernels on an NQA_PREC_F32M blob): the same tile choices on the NTERM = 2 instances; the
 // register-weights kernels hold one-term fragments only, so every layer takes the implicit GEMM here
 template <typename P>
-static int launch_conv_2term(const void *in, int n, int H, int W, const ConvSpec &cs, const char *wpk,
-                             const float *bias, void *out, bool narrow, bool big, hipStream_t st) {
+static int launch_conv_2term(const void *in, int n, int H, int W, int layer, const char *packed, int blob_prec,
+                             const ConvSpec &cs, const char *wpk, const float *bias, void *out, bool narrow, bool big,
+                             hipStream_t st) {
   if constexpr (sizeof(typename P::T) == 2 && P::ID == NQA_PREC_F16) {
+    // layers 1..4 with the weights in registers, as in the one-term 16-bit modes (first-form bits: the implicit GEMM)
+    if (W >= 16 && !g_first_forms) {
+      if (layer == 1) return launch_regw<P, 2, 2>(in, n, H, W, layer, packed, out, st, blob_prec);
+      if (layer == 2) return launch_regw<P, 4, 2>(in, n, H, W, layer, packed, out, st, blob_prec);
+      if ((layer == 3 || layer == 4) && !g_no_regw128) return launch_regw128<P, 2>(in, n, H, W, layer, packed, out, st, blob_prec);
+    }
 #define NQA_GO2(WN, WM, TN, TM, M16)                                                                                \
   return narrow ? launch_igemm<P, WN, WM, TN, TM, 16, M16, 2>(in, n, H, W, cs.cin, cs.cout, wpk, bias, out, 0, st) \
                 : launch_igemm<P, WN, WM, TN, TM, 32, M16, 2>(in, n, H, W, cs.cin, cs.cout, wpk, bias, out, 0, st)
@@ -1926,7 +1986,7 @@ static int launch_conv(const void *in, int n, int H, int W, int layer, const cha
     const long blocks_big = (long)cdiv(W, 32) * cdiv(H, 8) * n * (cs.cout / 256);
     if (blocks_big < 192) big = false;
   }
-  if (nterm == 2) return launch_conv_2term<P>(in, n, H, W, cs, wpk, bias, out, narrow, big, st);
+  if (nterm == 2) return launch_conv_2term<P>(in, n, H, W, layer, packed, blob_prec, cs, wpk, bias, out, narrow, big, st);
   // 8-wave 128 ch x 512 px tiles: the loop is bound by what a CU can take in per clock (weights
   // 3*BN*64 B + halo per stage), and for the same 64 K accumulators 128 x 512 moves 37.6 KB per
   // stage where 256 x 256 moves 56 KB and two 128 x 128 blocks move 58 KB.
@@ -1949,7 +2009,7 @@ static int launch_conv(const void *in, int n, int H, int W, int layer, const cha
   if constexpr (sizeof(typename P::T) == 2) {
     // conv2_1: register-resident weights (first-form bit of nqa_set_conv_variant: the implicit GEMM, for A/B runs)
     if (blob_prec == P::ID) {  // (their fragments live in the 16-bit blobs only)
-      if (layer == 2 && !g_first_forms && W >= 16) return launch_regw<P>(in, n, H, W, layer, packed, out, st);
+      if (layer == 2 && !g_first_forms && W >= 16) return launch_regw<P, 4, 1>(in, n, H, W, layer, packed, out, st);
       if ((layer == 3 || layer == 4) && !g_no_regw128 && !g_first_forms && W >= 16)
         return launch_regw128<P>(in, n, H, W, layer, packed, out, st);
     }
@@ -2031,14 +2091,14 @@ static int launch_conv1_tile(const float *x, const float *y, int B, int n, int H
   return check_launch("conv1_tile");
 }
 
-template <typename P>
+template <typename P, int NTERM = 1>
 static int launch_conv1_regw(const float *x, const float *y, int B, int n, int H, int W, const char *packed, void *out,
-                             hipStream_t st) {
-  constexpr int LDS = 2 * 2 * 352 * 96 + 2 * 13 * 40 * 8 + 4 * 2 * 64 * 16 + 256;
+                             hipStream_t st, int blob_prec = P::ID) {
+  constexpr int LDS = 2 * 2 * 352 * 96 + 2 * 13 * 40 * 8 + NTERM * 4 * 2 * 64 * 16 + 256;
   static std::atomic<bool> attr_done_dev[64];
   std::atomic<bool> &attr_done = attr_done_dev[current_device() & 63];
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv1_regw_kernel<P>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv1_regw_kernel<P, NTERM>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
       set_error("conv1_regw: cannot raise the dynamic LDS limit to %d bytes", LDS);
       return NQA_E_LAUNCH;
@@ -2052,12 +2112,15 @@ static int launch_conv1_regw(const float *x, const float *y, int B, int n, int H
   }
   const int tiles_x = cdiv(W, 32), tiles_y = cdiv(H, 8), total = n * tiles_x * tiles_y;
   const int grid = total < cus ? total : cus;
-  const float *b1 = reinterpret_cast<const float *>(packed + layer_bias_offset(0, P::ID));
-  const float *b2 = reinterpret_cast<const float *>(packed + layer_bias_offset(1, P::ID));
+  const float *b1 = reinterpret_cast<const float *>(packed + layer_bias_offset(0, blob_prec));
+  const float *b2 = reinterpret_cast<const float *>(packed + layer_bias_offset(1, blob_prec));
+  // two-term: 1 / conv1_1's weight scale sits in the first float of the (otherwise unused) 32x32 fragment area
+  const float *w1inv = reinterpret_cast<const float *>(packed + layer0_mfma_offset(blob_prec));
   TimedLaunch t(NQA_K_CONV, st);
-  conv1_regw_kernel<P><<<grid, 512, LDS, st>>>(x, y, B, packed + layer0_m16_offset(P::ID), b1,
-                                               packed + regw_offset(1, P::ID), b2,
-                                               reinterpret_cast<typename P::T *>(out), H, W, tiles_x, tiles_y, total);
+  conv1_regw_kernel<P, NTERM><<<grid, 512, LDS, st>>>(x, y, B, packed + layer0_m16_offset(blob_prec), b1,
+                                                      packed + regw_offset(1, blob_prec), b2,
+                                                      reinterpret_cast<typename P::T *>(out), H, W, tiles_x, tiles_y,
+                                                      total, w1inv);
   return check_launch("conv1_regw");
 }
 
@@ -2106,6 +2169,16 @@ int conv3x3_blob(const void *in, int n, int H, int W, int layer, const void *pac
   }
   set_error("conv3x3_blob: unsupported blob / kernel precision pair %d / %d", blob_prec, kprec);
   return NQA_E_ARG;
+}
+
+// stage 1 of the mixed mode in one kernel (two-term conv1_1 and conv1_2), images [x(0..B), y(0..n-B))
+int conv1_fused_blob(const float *x, const float *y, int B, int n, int H, int W, const void *packed, int blob_prec,
+                     void *out, hipStream_t st) {
+  if (blob_prec != NQA_PREC_F32M) {
+    set_error("conv1_fused_blob: NQA_PREC_F32M blobs only");
+    return NQA_E_ARG;
+  }
+  return launch_conv1_regw<PrecF16, 2>(x, y, B, n, H, W, static_cast<const char *>(packed), out, st, blob_prec);
 }
 
 int conv1_1_blob(const float *x, int n, int H, int W, const void *packed, int blob_prec, int kprec, void *out,

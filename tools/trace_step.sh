@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-$PWD}; WL=${1:-256}
 OUT=$R/gpurun_out/trace_tmp; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 $R/bench.py --workload $WL --steps 6 --warmup 2 --no-cpu-baseline > /dev/null 2> $OUT/err.txt
+rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 $R/bench.py --workload $WL --steps 6 --warmup 2 --no-cpu-baseline --only ${2:+--precision $2} > /dev/null 2> $OUT/err.txt
 python3 - <<PY
 import csv,glob,collections
 f=glob.glob("$OUT/*/*_kernel_trace.csv")[0]
