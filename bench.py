@@ -18,14 +18,15 @@ shard across ranks with no data-path collective; the only exchange is ONE all-ga
 after the last step (inside the timed region) -- weak scaling, K steps of 8 pairs on every GPU.
 
 At N=1 the same JSON line also carries, under "workloads", the rest of the metric ("1080p & 256^2", DISTS
-and A-DISTS) measured the same way in the same process: 1080p in f32s (float32 activations, split-f16
-products: the reference's own precision class), 256x256 B=32 (configs[1]) in f16 and f32s, and A-DISTS at
-1080p B=8 (configs[4], f32s).  Every entry has its own `roofline` (the MFMA implicit-GEMM conv stack:
-algorithmic FLOPs of layers 1..12 / the HIP-event time of those launches, measured inside the timed region
-on the launch stream; `peak` is always the guide's dense 2.5 PFLOP/s f16 figure, and for f32s -- three f16
-MFMAs per algorithmic product -- both the algorithmic and the issued-MFMA fraction are given) and
-`roofline_hbm` (the HBM-bound L2-pool + statistics pass).  `roofline.traffic` comes from the committed
-rocprofv3 PMC summary of this same command (profiles/r02_traffic.json), per launch.
+and A-DISTS) measured the same way in the same process: 1080p in f32m (the mixed mode `auto` falls back to when f16
+fails its calibration: two MFMAs per product in conv layers 1..6, three behind) and in f32s (float32 activations,
+split-f16 products: the reference's own precision class, what `auto` runs when nothing faster is admitted), 256x256
+B=32 (configs[1]) in f16 / f32m / f32s, and A-DISTS at 1080p B=8 (configs[4], f32s).  Every entry has its own
+`roofline` (the MFMA conv stack: algorithmic FLOPs of layers 1..12 / the HIP-event time of those launches, measured
+inside the timed region on the launch stream; `peak` is always the guide's dense 2.5 PFLOP/s f16 figure, and for
+f32m / f32s both the algorithmic and the issued-MFMA fraction are given) and `roofline_hbm` (the HBM-bound L2-pool +
+statistics pass).  `roofline.traffic` comes from the committed rocprofv3 PMC summary of this same command
+(profiles/r03_traffic.json), per launch, and is withheld when the library that ran is not the profiled build.
 
 `--workload video10k` is BASELINE.json configs[3]: a 10 000-frame 1080p video whose frames are generated on
 the device per batch from seed = frame index, sharded over the ranks (strong scaling), one all-gather.
@@ -64,48 +65,87 @@ WORKLOADS = {
                           "seed = frame index, sharded over the ranks", B=8, H=1080, W=1920, metric="DISTS"),
 }
 # what the N=1 line measures beside the headline (workload key, precision)
-COMPANIONS = (("1080p", "f32s"), ("256", "f16"), ("256", "f32s"), ("adists1080p", "f32s"))
+COMPANIONS = (("1080p", "f32m"), ("1080p", "f32s"), ("256", "f16"), ("256", "f32m"), ("256", "f32s"),
+              ("adists1080p", "f32s"))
 PEAK_F16_TFLOPS = 2500.0  # dense f16/bf16 MFMA, MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3   # exact-f32 MFMA
 PEAK_HBM_GBS = 8000.0
-MFMA_PER_PRODUCT = {"f16": 1, "bf16": 1, "f32s": 3, "f32": 1}
+MFMA_PER_PRODUCT = {"f16": 1, "bf16": 1, "f32s": 3, "f32": 1}  # f32m: 2 for conv layers 1..6, 3 for 7..12
+MIXED_LAST_2TERM_LAYER = 6
+TRAFFIC_FILE = "profiles/r03_traffic.json"
 AUTO_REPORT = {}  # DISTS' one-time precision calibration (what `auto`, the shipped default, chose and on what evidence)
 
 
-def conv_flops_per_image(h, w):
-    """(igemm layers 1..12, conv1_1) algorithmic FLOPs = 2*9*Cin*Cout*Hk*Wk summed."""
+def conv_flops_per_image(h, w, prec=None):
+    """(igemm layers 1..12, conv1_1) algorithmic FLOPs = 2*9*Cin*Cout*Hk*Wk summed; with `prec` the
+    first figure is the ISSUED f16-MFMA FLOPs instead (terms per product: f32s 3; f32m 2 for layers 1..6, 3 behind)."""
     dims = ops.pyramid_dims(h, w)
     ig = 0
     for li in range(1, 13):
         hk, wk = dims[ops.CONV_STAGE[li]]
-        ig += 2 * 9 * ops.CONV_CIN[li] * ops.CONV_COUT[li] * hk * wk
+        terms = 1 if prec is None else (
+            (2 if li <= MIXED_LAST_2TERM_LAYER else 3) if prec == "f32m" else MFMA_PER_PRODUCT.get(prec, 1))
+        ig += terms * 2 * 9 * ops.CONV_CIN[li] * ops.CONV_COUT[li] * hk * wk
     return ig, 2 * 9 * 3 * 64 * h * w
 
 
-def pool_bytes_per_image(h, w, esz):
+def tap_elem_bytes(prec, k):
+    """(bytes per element of tapped map k+1, bytes per element of its pooled map) in mode `prec`."""
+    if prec == "f32m":  # half taps 1..3 (the pool behind tap 3 writes split16 records), float behind
+        return (2, 2 if k < 2 else 4) if k < 3 else (4, 4)
+    e = 2 if prec in ("f16", "bf16") else 4
+    return e, e
+
+
+def pool_bytes_per_image(h, w, prec):
     """Algorithmic HBM bytes of the pool+statistics pass per image: taps 1..4 read once, a quarter written
-    (SURVEY 8d, L2-pool row); esz = bytes per stored activation."""
+    (SURVEY 8d, L2-pool row), in the element sizes the mode stores them in."""
     dims = ops.pyramid_dims(h, w)
     total = 0
     for k in range(4):
         hk, wk = dims[k]
         c = ops.CHNS[k + 1]
-        total += hk * wk * c * esz + ((hk + 1) // 2) * ((wk + 1) // 2) * c * esz
+        ein, eout = tap_elem_bytes(prec, k)
+        total += hk * wk * c * ein + ((hk + 1) // 2) * ((wk + 1) // 2) * c * eout
     return total
 
 
 def load_traffic():
     """Committed PMC summary (rocprofv3 --pmc passes of this command, corrected as MI355X_MICROARCH.md's HBM
-    section prescribes: FETCH_SIZE doubled on gfx950): {workload/prec: {"conv": bytes per launch, "pool": ...}}."""
+    section prescribes: FETCH_SIZE doubled on gfx950): {workload/prec: {"conv": bytes per launch, "pool": ...}}.
+    The figures belong to the library build named in the file ("lib_sha16"); the line carries that and whether the
+    library it ran matches, so stale bytes are never shown as fresh ones."""
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+        t = json.load(open(os.path.join(ROOT, TRAFFIC_FILE)))
     except (OSError, ValueError):
         return {}
+    try:
+        import hashlib
+        from nerf_qa_amd import _lib
+        t["_lib_matches"] = hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()[:16] == t.get("lib_sha16")
+    except OSError:
+        t["_lib_matches"] = False
+    return t
+
+
+def traffic_for(traffic, key):
+    """The committed PMC bytes per launch of workload `key`, tagged with where they come from and whether the
+    profiled library is the one that just ran (None + the reason when there is nothing to show)."""
+    t = dict(traffic.get(key, {}))
+    if not t:
+        t["_source"] = f"none: {TRAFFIC_FILE} has no entry for {key}"
+    elif not traffic.get("_lib_matches"):
+        t = {"_source": f"withheld: {TRAFFIC_FILE} was measured on library build {traffic.get('lib_sha16')}, not the one "
+                        "that ran this line"}
+    else:
+        t["_source"] = f"{TRAFFIC_FILE} (rocprofv3 --pmc passes of this command on library build {traffic.get('lib_sha16')})"
+    return t
 
 
 def rooflines(ktimes, h, w, b, prec, traffic):
     """roofline (MFMA conv stack) and roofline_hbm (pool+statistics) from the HIP-event times of one timed run."""
     ig_flops, _ = conv_flops_per_image(h, w)
+    issued_flops, _ = conv_flops_per_image(h, w, prec)
     n_ig, ms_ig = ktimes["conv_igemm"]
     per_step = 12  # launches of class conv_igemm per step: layers 1..12 (16-bit modes: fused stage 1 + layers 2..12)
     steps = n_ig / per_step if n_ig else 0
@@ -113,26 +153,30 @@ def rooflines(ktimes, h, w, b, prec, traffic):
     peak = PEAK_F32_TFLOPS if prec == "f32" else PEAK_F16_TFLOPS
     roof = {
         "kernel": "VGG conv layers 1..12 on MFMA: conv1_regw_kernel (stage 1), conv3x3_regw_kernel / conv3x3_regw128_kernel "
-                  "(conv2_1 / conv2_2, conv3_1), conv3x3_igemm_kernel (the rest; all layers in f32 / f32s)",
+                  "(conv2_1 / conv2_2, conv3_1), conv3x3_igemm_kernel (the rest; all layers in f32 / f32s; f32m: the "
+                  "two-term instances of the first three for layers 1..4, two-term igemm for 5..6, f32s igemm for 7..12)",
         "bound": "mfma", "achieved": round(ach, 2) if ach else None, "peak": peak, "unit": "TFLOP/s",
         "frac": round(ach / peak, 4) if ach else None,
-        "traffic": traffic.get("conv"), "launches": n_ig, "avg_launch_ms": round(ms_ig / n_ig, 5) if n_ig else None,
+        "traffic": traffic.get("conv"), "traffic_source": traffic.get("_source"),
+        "launches": n_ig, "avg_launch_ms": round(ms_ig / n_ig, 5) if n_ig else None,
         "flop_per_launch_avg": round(ig_flops * 2 * b / per_step),
         "note": "achieved = algorithmic FLOPs / HIP-event time; peak = dense f16 MFMA (2.5 PF)" if prec != "f32" else
                 "exact-f32 MFMA; peak = 157.3 TF",
     }
-    if prec == "f32s" and ach:
-        roof["mfma_issued_tflops"] = round(3 * ach, 1)
-        roof["frac_of_issued_mfma"] = round(3 * ach / peak, 4)
-        roof["note"] = ("f32s issues three f16 MFMAs per algorithmic product (hi*hi + hi*lo + lo*hi): `frac` is "
-                        "algorithmic FLOP/s over the 2.5 PF f16 peak, `frac_of_issued_mfma` is the matrix cores' load")
+    if prec in ("f32s", "f32m") and ach:
+        issued = ach * issued_flops / ig_flops
+        roof["mfma_issued_tflops"] = round(issued, 1)
+        roof["frac_of_issued_mfma"] = round(issued / peak, 4)
+        roof["note"] = ("f32s issues three f16 MFMAs per algorithmic product (hi*hi + hi*lo + lo*hi), f32m two for conv "
+                        "layers 1..6 (activation x weight-hi, x weight-lo) and three behind: `frac` is algorithmic "
+                        "FLOP/s over the 2.5 PF f16 peak, `frac_of_issued_mfma` is the matrix cores' load")
     n_p, ms_p = ktimes["l2pool"]
-    esz = 2 if prec in ("f16", "bf16") else 4
-    ach_b = pool_bytes_per_image(h, w, esz) * 2 * b * steps / (ms_p * 1e-3) / 1e9 if ms_p > 0 and steps else None
+    ach_b = pool_bytes_per_image(h, w, prec) * 2 * b * steps / (ms_p * 1e-3) / 1e9 if ms_p > 0 and steps else None
     hbm = {"kernel": "pool_stats_kernel (L2-pool + the five statistics sums of taps 1..4, one pass)", "bound": "hbm",
            "achieved": round(ach_b, 1) if ach_b else None, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-           "frac": round(ach_b / PEAK_HBM_GBS, 4) if ach_b else None, "traffic": traffic.get("pool"), "launches": n_p,
-           "bytes_per_launch_avg": round(pool_bytes_per_image(h, w, esz) * 2 * b / 4)}
+           "frac": round(ach_b / PEAK_HBM_GBS, 4) if ach_b else None, "traffic": traffic.get("pool"),
+           "traffic_source": traffic.get("_source"), "launches": n_p,
+           "bytes_per_launch_avg": round(pool_bytes_per_image(h, w, prec) * 2 * b / 4)}
     kms = {k: round(v[1] / max(steps, 1), 4) for k, v in ktimes.items() if v[0]}
     return roof, hbm, kms
 
@@ -191,7 +235,7 @@ def make_model(metric, precision, dev, h, w):
     """-> (callable(ref, render) -> (B,) scores, the precision mode it runs this frame size in, weight source)."""
     if metric == "A-DISTS":
         net = ADISTS(precision=precision, vgg16_path=VGG).to(dev).eval()
-        return (lambda a, b: net(a, b, as_loss=False)), net.precision, net.vgg_source  # x = reference frame
+        return (lambda a, b: net(a, b, as_loss=False)), net.precision_for(h, w), net.vgg_source  # x = reference frame
     net = DISTS(precision=precision, vgg16_path=VGG).to(dev).eval()
     prec = net.precision_for(h, w)  # "auto" (the default) calibrates f16 against f32s with these weights, once
     if net.precision == "auto":
@@ -330,7 +374,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=sorted(WORKLOADS) + ["stub"], default="1080p",
                     help="1080p (default, BASELINE configs[2]) | 256 | adists1080p | adists256 | video10k")
-    ap.add_argument("--precision", default=None, help="f16 (DISTS default), f32s (A-DISTS default), f32, bf16")
+    ap.add_argument("--precision", default=None, help="default: DISTS auto (calibrated f16 / f32m / f32s), A-DISTS f32s; "
+                                                      "or one of f16, f32m, f32s, f32, bf16")
     ap.add_argument("--only", action="store_true", help="skip the companion workloads of the N=1 line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=0, help="override pairs per GPU per step (experiments only)")
@@ -396,7 +441,7 @@ def main():
         dt, ktimes, prec, H, W, src, cols = run_video(args.frames, args.precision, args.warmup, dev, world, rank, batch)
         dt, per = rank_times(dt)
         if rank == 0:
-            roof, hbm, kms = rooflines(ktimes, H, W, batch, prec, traffic.get(f"1080p/{prec}", {}))
+            roof, hbm, kms = rooflines(ktimes, H, W, batch, prec, traffic_for(traffic, f"1080p/{prec}"))
             # this rank's launches cover its own shard only: per-launch figures stay valid, per-step ones are per batch
             per_rank = -(-args.frames // world)
             nsteps = max(1, -(-per_rank // batch))
@@ -420,7 +465,7 @@ def main():
     dt, per = rank_times(dt)
     out = None
     if rank == 0:
-        roof, hbm, kms = rooflines(ktimes, H, W, B, prec, traffic.get(f"{args.workload}/{prec}", {}))
+        roof, hbm, kms = rooflines(ktimes, H, W, B, prec, traffic_for(traffic, f"{args.workload}/{prec}"))
         out = {
             "metric": wl["metric"] + " frame-pairs/s",
             "value": round(world * B * args.steps / dt, 2),
@@ -448,7 +493,7 @@ def main():
         comp = {}
         for key, cprec in COMPANIONS:
             cdt, ckt, cp, cb, ch, cw, _ = run_workload(key, cprec, args.steps, args.warmup, dev, 1, 0)
-            croof, chbm, ckms = rooflines(ckt, ch, cw, cb, cp, traffic.get(f"{key}/{cp}", {}))
+            croof, chbm, ckms = rooflines(ckt, ch, cw, cb, cp, traffic_for(traffic, f"{key}/{cp}"))
             comp[f"{key}/{cp}"] = {"workload": WORKLOADS[key]["name"], "metric": WORKLOADS[key]["metric"] + " frame-pairs/s",
                                    "value": round(cb * args.steps / cdt, 2), "unit": "frame-pairs/s",
                                    "ms_per_step": round(cdt / args.steps * 1e3, 4), "dtype": cp,

@@ -7,9 +7,10 @@ Mirrors nerf_qa/ADISTS/ADISTS.py:
 Asymmetric like the reference: texture probabilities and entropy weights come from x
 only (:147,153), so callers pass x = reference frame (prep.py:186).
 
-Precision: the default here is "f32s": float32 activations, convolutions on the f16 matrix cores
-with both operands split into (hi, lo) half pairs (3 MFMAs per product) -- 1e-7 from the exact-f32
-path and from the reference, at ~1.9x the exact-f32 ("f32") throughput.  Plain 16-bit features are
+Precision: the default here is "auto" = "f32s" for frames of at least 128x128 pixels -- float32 activations,
+convolutions on the f16 matrix cores with both operands split into (hi, lo) half pairs (3 MFMAs per
+product), 1e-7 from the exact-f32 path and from the reference at ~1.9x the exact-f32 ("f32") throughput --
+and exact "f32" below (see AUTO_EXACT_PIXELS).  Plain 16-bit features are
 NOT safe for A-DISTS: F.normalize (:166-167) and the entropy weights (:127-135) rescale every channel by
 its own L2 norm, so a channel that is dead except for one pixel at 1e-4 is a full-scale feature
 after normalisation, and the same channel rounded to exactly dead contributes T = S = 1 -- one such
@@ -34,8 +35,18 @@ from .. import ops
 from .._lib import prec_id
 from ..DISTS_pytorch.DISTS_pt import L2pooling as Downsample, _build_stages  # noqa: F401
 
-DEFAULT_PRECISION = "f32s"
 from ..vgg_weights import load_vgg16_convs
+
+# "auto" (the default): frames of fewer than AUTO_EXACT_PIXELS pixels run in "f32" (exact-f32 MFMA products, the
+# reference's own 24-bit arithmetic), larger ones in "f32s" (22-23 bits, ~1.9x the conv throughput).  A-DISTS is
+# discontinuous where a channel is dead except for a pixel or two (F.normalize, ADISTS.py:166-167): on frames of a few
+# dozen pixels a side such channels are common and whether one survives can hinge on the last bit of a
+# pre-activation -- round 2 found a 22x68 pair whose f32s score moved by 4.9e-4 when nothing but the summation order
+# inside conv1_1 changed.  Below the threshold the cost of exact products is irrelevant (a 128x128 frame is
+# launch-bound either way); above it no pair of ~5 900 random ones has moved by more than 6.4e-5
+# (profiles/r02_stress_final.txt), and tools/gpu_stress.py now re-checks that with both conv1_1 forms.
+DEFAULT_PRECISION = "auto"
+AUTO_EXACT_PIXELS = 128 * 128
 
 
 class ADISTS(torch.nn.Module):
@@ -56,11 +67,10 @@ class ADISTS(torch.nn.Module):
         for k in range(len(self.chns)):
             self.windows.append(self.create_window(self.window_size, self.window_size / 3, self.chns[k]))
         self.precision = precision or os.environ.get("NQA_ADISTS_PRECISION", DEFAULT_PRECISION)
-        if prec_id(self.precision) == 4:
+        if self.precision != "auto" and prec_id(self.precision) == 4:
             raise ValueError("precision 'f32m' is a DISTS mode: A-DISTS needs float precision in every layer "
-                             "(see the module docstring); use 'f32s' (default), 'f32' or the opt-in 'f16'")
-        self._packed = None
-        self._packed_key = None
+                             "(see the module docstring); use 'auto' (default), 'f32s', 'f32' or the opt-in 'f16'")
+        self._packed = {}
         self._ws = ops.Workspace()
 
     # the window parameters are kept for state_dict compatibility (ADISTS.py:66-69,102-110);
@@ -79,17 +89,24 @@ class ADISTS(torch.nn.Module):
         return [m for st in (self.stage1, self.stage2, self.stage3, self.stage4, self.stage5)
                 for m in st if isinstance(m, nn.Conv2d)]
 
-    def _packed_weights(self, dev):
+    def precision_for(self, h: int, w: int) -> str:
+        """The precision mode a frame size runs in ("auto": exact f32 below AUTO_EXACT_PIXELS pixels, f32s above)."""
+        if self.precision != "auto":
+            return self.precision
+        return "f32" if h * w < AUTO_EXACT_PIXELS else "f32s"
+
+    def _packed_weights(self, dev, prec):
         convs = self._conv_modules()
-        key = (str(dev), self.precision) + tuple((m.weight._version, m.weight.data_ptr()) for m in convs)
-        if self._packed is None or self._packed_key != key:
-            blob = ops.pack_vgg_weights([(m.weight, m.bias) for m in convs], self.precision)
-            self._packed, self._packed_key = blob.to(dev), key
-        return self._packed
+        key = (str(dev),) + tuple((m.weight._version, m.weight.data_ptr()) for m in convs)
+        hit = self._packed.get(prec)
+        if hit is None or hit[0] != key:
+            blob = ops.pack_vgg_weights([(m.weight, m.bias) for m in convs], prec)
+            hit = self._packed[prec] = (key, blob.to(dev))
+        return hit[1]
 
     def __getstate__(self):
         d = self.__dict__.copy()
-        for k in ("_packed", "_packed_key", "_ws"):  # device scratch never travels (__setstate__ rebuilds it)
+        for k in ("_packed", "_ws"):  # device scratch never travels (__setstate__ rebuilds it)
             d.pop(k, None)
         return d
 
@@ -98,11 +115,13 @@ class ADISTS(torch.nn.Module):
         d = self.__dict__
         d.setdefault("precision", os.environ.get("NQA_ADISTS_PRECISION", DEFAULT_PRECISION))
         d.setdefault("vgg_source", "unpickled module (Conv2d weights of stage1..5)")
-        d["_packed"], d["_packed_key"], d["_ws"] = None, None, ops.Workspace()
+        d.pop("_packed_key", None)
+        d["_packed"], d["_ws"] = {}, ops.Workspace()
 
     def forward_once(self, x):
-        taps = ops.vgg_pyramid(x, self._packed_weights(x.device), self.precision, self._ws)
-        return [x] + [ops.nhwc_to_nchw_f32(t, self.precision) for t in taps]
+        prec = self.precision_for(x.shape[-2], x.shape[-1])
+        taps = ops.vgg_pyramid(x, self._packed_weights(x.device, prec), prec, self._ws)
+        return [x] + [ops.nhwc_to_nchw_f32(t, prec) for t in taps]
 
     def forward(self, x, y, as_loss=True, as_map=False):
         assert x.shape == y.shape
@@ -110,13 +129,14 @@ class ADISTS(torch.nn.Module):
             raise NotImplementedError("ADISTS(as_loss=True) on grad-requiring inputs needs a backward pass through "
                                       "the VGG pyramid (ADISTS.py:139-141), which this build does not have; call it "
                                       "under torch.no_grad() or with as_loss=False for the value")
+        prec = self.precision_for(x.shape[-2], x.shape[-1])
         if as_map:
             # (:163,188-189,193) the reference's (B,H,W) + (B,1,H,W) addition broadcasts to (B,B,H,W)
             # with out[i, j] = map[i]; reproduced as is (callers use B = 1, nerf_nr_qa_prep_4.py:70)
-            _, m = ops.adists_forward(x, y, self._packed_weights(x.device), self.precision, self._ws, with_map=True)
+            _, m = ops.adists_forward(x, y, self._packed_weights(x.device, prec), prec, self._ws, with_map=True)
             b = m.shape[0]
             return m.unsqueeze(1).expand(b, b, *m.shape[1:]).contiguous()
-        d = ops.adists_forward(x, y, self._packed_weights(x.device), self.precision, self._ws)
+        d = ops.adists_forward(x, y, self._packed_weights(x.device, prec), prec, self._ws)
         if as_loss:
             return 1 - d.mean()
         return 1 - d

@@ -79,14 +79,14 @@ def test_module_pickled_without_this_builds_private_fields(alias):
     from nerf_qa.ADISTS import ADISTS
     from nerf_qa.DISTS_pytorch.DISTS_pt import DISTS
     for cls, priv in ((DISTS, ("precision", "vgg_source", "_packed", "_ws")),
-                      (ADISTS, ("precision", "vgg_source", "_packed", "_packed_key", "_ws"))):
+                      (ADISTS, ("precision", "vgg_source", "_packed", "_ws"))):
         m = cls(vgg16_path="synth:1234")
         state = {k: v for k, v in m.__dict__.items() if k not in priv}
         back = cls.__new__(cls)
         back.__setstate__(state)
         for k in priv:
             assert hasattr(back, k), (cls, k)
-        assert len(back._conv_modules()) == 13 and back.precision in ("auto", "f32s")
+        assert len(back._conv_modules()) == 13 and back.precision == "auto"
 
 
 def test_without_alias_the_reference_names_do_not_resolve():

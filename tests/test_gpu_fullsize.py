@@ -38,7 +38,8 @@ def models(dev):
         assert d.precision_for(256, 256) == "f16" and d.precision_for(1080, 1920) == "f16"
         with pytest.raises(Exception):
             DISTS().precision_for(256, 256)  # on the CPU there is nothing to calibrate on
-        assert ADISTS().precision == "f32s"
+        a = ADISTS()
+        assert a.precision == "auto" and a.precision_for(1080, 1920) == "f32s" and a.precision_for(64, 64) == "f32"
         return m
 
 

@@ -139,7 +139,7 @@ def test_adists_1080p_b8_vs_reference(gain, dev):
     slots = (0, 7)
     x, y = _batch_with(gx, gy, slots, 8, dev)
     m = ADISTS(vgg16_path=_spec(gain)).to(dev).eval()
-    assert m.precision == "f32s"
+    assert m.precision == "auto" and m.precision_for(1080, 1920) == "f32s" and m.precision_for(22, 68) == "f32"
     with torch.no_grad():
         got = m(x, y, as_loss=False)
         again = m(x, y, as_loss=False)
@@ -223,15 +223,21 @@ def test_rccl_one_rank():
 def test_former_knife_edge_pairs(dev):
     """The four pairs on which round 1's f32s A-DISTS sat 4e-4 from the oracle (tools/gpu_stress.py).  The imported
     reference returns the same value for them in f32 with 8 threads / 1 thread / oneDNN off / channels_last and in
-    float64 (oracle/knife_edge_study.py; spread <= 2.3e-7), so that value is THE answer and the HIP default must match."""
+    float64 (oracle/knife_edge_study.py; spread <= 2.3e-7), so that value is THE answer and the HIP default must match.
+    The default is "auto": frames this small run with exact-f32 products, so the match no longer hangs on the rounding
+    pattern of one kernel (round 2: an equally accurate conv1_1 of another summation order flipped the 22x68 pair in
+    f32s); f32s on them is recorded beside it."""
     from nerf_qa_amd import synth
     from nerf_qa_amd.ADISTS import ADISTS
     g = np.load(os.path.join(GOLDEN, "knife_edge_adists.npz"))
     assert (g["reference"].max(1) - g["reference"].min(1)).max() <= 1e-6
     m = ADISTS(vgg16_path="synth:1234").to(dev).eval()
+    ms = ADISTS(vgg16_path="synth:1234", precision="f32s").to(dev).eval()
     for h, w, seed, kind, ref in zip(g["h"], g["w"], g["seed"], g["kind"], g["reference"]):
         x, y = synth.frame_pair(int(seed), int(h), int(w), str(kind))
+        assert m.precision_for(int(h), int(w)) == "f32"
         with torch.no_grad():
             got = m(torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev), as_loss=False).item()
-        print(f"\n{h}x{w} seed {seed}: hip {got:.7f} reference {ref[0]:.7f} (f64 {ref[-1]:.7f})")
+            got_s = ms(torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev), as_loss=False).item()
+        print(f"\n{h}x{w} seed {seed}: hip auto(f32) {got:.7f} f32s {got_s:.7f} reference {ref[0]:.7f} (f64 {ref[-1]:.7f})")
         assert abs(got - float(ref[0])) <= 2e-5, (h, w, seed, got, ref)

@@ -25,7 +25,8 @@ def models():
         warnings.simplefilter("ignore")
         return {"f16": DISTS(precision="f16").to(dev).eval(), "f32s": DISTS(precision="f32s").to(dev).eval(),
                 "f32m": DISTS(precision="f32m").to(dev).eval(),
-                "bf16": DISTS(precision="bf16").to(dev).eval(), "a32s": ADISTS().to(dev).eval()}
+                "bf16": DISTS(precision="bf16").to(dev).eval(), "a32s": ADISTS(precision="f32s").to(dev).eval(),
+                "a_auto": ADISTS().to(dev).eval()}
 
 
 @pytest.mark.parametrize("h,w", SHAPES, ids=[f"{h}x{w}" for h, w in SHAPES])
@@ -50,6 +51,10 @@ def test_random_shape(h, w, models, oracle_convs):
         assert torch.equal(torch.isnan(got), torch.isnan(aref)), ("a32s", h, w, got, aref)
         ok = ~torch.isnan(aref)
         assert not ok.any() or (got[ok] - aref[ok]).abs().max().item() <= 2e-5, ("a32s", h, w, got, aref)
+        # the shipped default (exact f32 below 128x128 pixels, f32s above)
+        got = models["a_auto"](x.to(dev), y.to(dev), as_loss=False).cpu()
+        assert torch.equal(torch.isnan(got), torch.isnan(aref)), ("a_auto", h, w, got, aref)
+        assert not ok.any() or (got[ok] - aref[ok]).abs().max().item() <= 2e-5, ("a_auto", h, w, got, aref)
 
 
 class _GuardedWorkspace:

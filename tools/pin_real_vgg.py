@@ -96,7 +96,7 @@ def main():
                 got = (m(x.to(dev), y.to(dev), as_loss=False) if adists else m(x.to(dev), y.to(dev))).cpu()
             ok = ~torch.isnan(ref)
             e = float((got[ok] - ref[ok]).abs().max())
-            name = mode if mode != "default" else "default=" + (m.precision if adists else m.precision_for(h, w, dev))
+            name = mode if mode != "default" else "default=" + (m.precision_for(h, w) if adists else m.precision_for(h, w, dev))
             out[name] = e
             line += f" | {name} {e:.2e}"
             if mode == "default" and e > BAR:
