@@ -646,10 +646,17 @@ __global__ __launch_bounds__(512) void conv3x3_regw_kernel(const typename P::T *
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
     const int j = r * 512 + tid, q = j >> 2;
-    p_c[r] = (j & 3) ^ lds_swz<true>(q);
     p_hy[r] = q < NQ ? q / HWD : -100000;  // items past the patch: never inside any image
     p_hx[r] = q - (q / HWD) * HWD;
+    // the chunk swizzle goes by the pixel's COLUMN in the patch, not by its linear index: equally conflict-free
+    // (a row of the patch only shifts the phase of the pattern), and a tap's LDS address is then one per-lane
+    // constant per kx plus compile-time offsets -- no address arithmetic in the k loop (see tap_base below)
+    p_c[r] = (j & 3) ^ lds_swz<true>(p_hx[r]);
   }
+  // per-lane byte offset of this lane's fragment of patch column l15 + kx (any patch row, 16-pixel group 0)
+  int tap_base[3];
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx) tap_base[kx] = (l15 + kx) * 64 + ((c4 ^ lds_swz<true>(l15 + kx)) << 4);
   const unsigned kOOB = 0x80000000u;
   const unsigned img_in_bytes = (unsigned)H * (unsigned)W * 64u * (unsigned)sizeof(T);
   const unsigned img_out_bytes = (unsigned)H * (unsigned)W * (unsigned)COUT * (unsigned)sizeof(T);
@@ -687,17 +694,17 @@ __global__ __launch_bounds__(512) void conv3x3_regw_kernel(const typename P::T *
       asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NPIECE) : "memory");
     else
       asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NPIECE + NSTORE) : "memory");
-    const char *slot = smem + (it % 3) * SLOT;
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
         out + (size_t)n * H * W * COUT, 0, img_out_bytes, 0x00020000);
 #pragma unroll 1
     for (int pass = 0; pass < NPASS; ++pass) {
-      int q0[GPP];  // halo pixel of this lane's output pixel at tap (0,0), per 16-pixel group
+      // this pass's tile row: three address registers (one per kx), every tap / chunk / pixel group an immediate offset
+      int rowb[3];
 #pragma unroll
-      for (int g = 0; g < GPP; ++g) q0[g] = (ph * RW + pass) * HWD + g * 16 + l15;
-      // opaque per pass: otherwise hipcc hoists the 72 fragment addresses of the unrolled k loop out of the
+      for (int kx = 0; kx < 3; ++kx) rowb[kx] = tap_base[kx] + (it % 3) * SLOT + (ph * RW + pass) * (HWD * 64);
+      // opaque per pass: otherwise hipcc hoists the fragment addresses of the unrolled k loop out of the
       // persistent tile loop and spills the weight registers
-      asm volatile("" : "+v"(q0[0]), "+v"(q0[1]));
+      asm volatile("" : "+v"(rowb[0]), "+v"(rowb[1]), "+v"(rowb[2]));
       f32x4 acc[2][GPP];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -709,10 +716,8 @@ __global__ __launch_bounds__(512) void conv3x3_regw_kernel(const typename P::T *
       auto load_b = [&](int ks, u32x4(&b)[GPP]) {
         const int cc = ks / 9, t = ks - cc * 9, ky = t / 3, kx = t - ky * 3;
 #pragma unroll
-        for (int g = 0; g < GPP; ++g) {
-          const int q = q0[g] + ky * HWD + kx;
-          b[g] = *reinterpret_cast<const u32x4 *>(slot + cc * CH_BYTES + q * 64 + ((c4 ^ lds_swz<true>(q)) << 4));
-        }
+        for (int g = 0; g < GPP; ++g)
+          b[g] = *reinterpret_cast<const u32x4 *>(smem + rowb[kx] + (cc * CH_BYTES + ky * (HWD * 64) + g * 1024));
       };
       load_b(0, bf[0]);
 #pragma unroll
@@ -835,10 +840,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_regw128_kernel(const typename 
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int j = r * 256 + tid, q = j >> 2;
-    p_c[r] = (j & 3) ^ lds_swz<true>(q);
     p_hy[r] = q < NQ ? q / HWD : -100000;
     p_hx[r] = q - (q / HWD) * HWD;
+    p_c[r] = (j & 3) ^ lds_swz<true>(p_hx[r]);  // swizzled by the patch COLUMN (see conv3x3_regw_kernel)
   }
+  int tap_base[3];  // per-lane byte offset of the fragment of patch column l15 + kx
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx) tap_base[kx] = (l15 + kx) * 64 + ((c4 ^ lds_swz<true>(l15 + kx)) << 4);
   const unsigned kOOB = 0x80000000u;
   const unsigned img_in_bytes = (unsigned)H * (unsigned)W * (unsigned)CIN * (unsigned)sizeof(T);
   const unsigned img_out_bytes = (unsigned)H * (unsigned)W * (unsigned)Cout * (unsigned)sizeof(T);
@@ -877,15 +885,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_regw128_kernel(const typename 
     else
       asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NSTORE) : "memory");
     issue_halo(it + 1, (it + 1) & 1);  // that slot was last read during tile it-1
-    const char *slot = smem + (it & 1) * SLOT;
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
         out + (size_t)n * H * W * Cout, 0, img_out_bytes, 0x00020000);
 #pragma unroll 1
     for (int pass = 0; pass < NPASS; ++pass) {
-      int q0[GPP];
+      int rowb[3];  // this pass's tile row: one address register per kx, everything else an immediate offset
 #pragma unroll
-      for (int g = 0; g < GPP; ++g) q0[g] = pass * HWD + g * 16 + l15;
-      asm volatile("" : "+v"(q0[0]), "+v"(q0[1]));
+      for (int kx = 0; kx < 3; ++kx) rowb[kx] = tap_base[kx] + (it & 1) * SLOT + pass * (HWD * 64);
+      asm volatile("" : "+v"(rowb[0]), "+v"(rowb[1]), "+v"(rowb[2]));
       f32x4 acc[2][GPP];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -895,10 +902,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_regw128_kernel(const typename 
       auto load_b = [&](int ks, u32x4(&b)[GPP]) {
         const int cc = ks / 9, t = ks - cc * 9, ky = t / 3, kx = t - ky * 3;
 #pragma unroll
-        for (int g = 0; g < GPP; ++g) {
-          const int q = q0[g] + ky * HWD + kx;
-          b[g] = *reinterpret_cast<const u32x4 *>(slot + cc * CH_BYTES + q * 64 + ((c4 ^ lds_swz<true>(q)) << 4));
-        }
+        for (int g = 0; g < GPP; ++g)
+          b[g] = *reinterpret_cast<const u32x4 *>(smem + rowb[kx] + (cc * CH_BYTES + ky * (HWD * 64) + g * 1024));
       };
 #pragma unroll
       for (int ks = 0; ks < PF; ++ks) load_b(ks, bf[ks]);
