@@ -71,7 +71,7 @@ PEAK_F16_TFLOPS = 2500.0  # dense f16/bf16 MFMA, MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3   # exact-f32 MFMA
 PEAK_HBM_GBS = 8000.0
 MFMA_PER_PRODUCT = {"f16": 1, "bf16": 1, "f32s": 3, "f32": 1}  # f32m: 2 for conv layers 1..6, 3 for 7..12
-MIXED_LAST_2TERM_LAYER = 6
+MIXED_LAST_2TERM_LAYER = {"f32m": 6, "f32m2": 3}
 TRAFFIC_FILE = "profiles/r03_traffic.json"
 AUTO_REPORT = {}  # DISTS' one-time precision calibration (what `auto`, the shipped default, chose and on what evidence)
 
@@ -84,15 +84,16 @@ def conv_flops_per_image(h, w, prec=None):
     for li in range(1, 13):
         hk, wk = dims[ops.CONV_STAGE[li]]
         terms = 1 if prec is None else (
-            (2 if li <= MIXED_LAST_2TERM_LAYER else 3) if prec == "f32m" else MFMA_PER_PRODUCT.get(prec, 1))
+            (2 if li <= MIXED_LAST_2TERM_LAYER[prec] else 3) if prec in MIXED_LAST_2TERM_LAYER else MFMA_PER_PRODUCT.get(prec, 1))
         ig += terms * 2 * 9 * ops.CONV_CIN[li] * ops.CONV_COUT[li] * hk * wk
     return ig, 2 * 9 * 3 * 64 * h * w
 
 
 def tap_elem_bytes(prec, k):
     """(bytes per element of tapped map k+1, bytes per element of its pooled map) in mode `prec`."""
-    if prec == "f32m":  # half taps 1..3 (the pool behind tap 3 writes split16 records), float behind
-        return (2, 2 if k < 2 else 4) if k < 3 else (4, 4)
+    if prec in ("f32m", "f32m2"):  # half taps 1..3 | 1..2 (the pool behind the last one writes split16 records), float behind
+        ms = 3 if prec == "f32m" else 2
+        return (2, 2 if k < ms - 1 else 4) if k < ms else (4, 4)
     e = 2 if prec in ("f16", "bf16") else 4
     return e, e
 
@@ -163,7 +164,7 @@ def rooflines(ktimes, h, w, b, prec, traffic):
         "note": "achieved = algorithmic FLOPs / HIP-event time; peak = dense f16 MFMA (2.5 PF)" if prec != "f32" else
                 "exact-f32 MFMA; peak = 157.3 TF",
     }
-    if prec in ("f32s", "f32m") and ach:
+    if prec in ("f32s", "f32m", "f32m2") and ach:
         issued = ach * issued_flops / ig_flops
         roof["mfma_issued_tflops"] = round(issued, 1)
         roof["frac_of_issued_mfma"] = round(issued / peak, 4)

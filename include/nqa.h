@@ -53,9 +53,13 @@ extern "C" {
  * with weights held as f16 (hi, lo) pairs -- TWO MFMAs per product, the weights' 11-bit rounding removed -- and
  * stages 4..5 (layers 7..12) run as NQA_PREC_F32S; the L2-pool after stage 3 turns the f16 tap into split16
  * records.  Taps 1..3 are half, taps 4..5 float.  What is left of the 16-bit error is the activation rounding of the
- * first seven layers, whose contribution to a DISTS score is the smallest of all (tools/cpu_prec_layers.py). */
-enum { NQA_PREC_F32 = 0, NQA_PREC_BF16 = 1, NQA_PREC_F16 = 2, NQA_PREC_F32S = 3, NQA_PREC_F32M = 4 };
-#define NQA_MIXED_STAGES 3 /* NQA_PREC_F32M: pyramid stages (1-based) run with f16 activations + two-term weights */
+ * first seven layers, whose contribution to a DISTS score is the smallest of all (tools/cpu_prec_layers.py).
+ *
+ * NQA_PREC_F32M2: the same with only stages 1..2 (conv layers 0..3) on two-term weights and stages 3..5 as
+ * NQA_PREC_F32S (taps 1..2 half, 3..5 float): 2.6 times less of that residual error for ~10 % of the speed. */
+enum { NQA_PREC_F32 = 0, NQA_PREC_BF16 = 1, NQA_PREC_F16 = 2, NQA_PREC_F32S = 3, NQA_PREC_F32M = 4, NQA_PREC_F32M2 = 5 };
+/* pyramid stages (1-based count) that run with f16 activations + two-term weights in a mixed mode, 0 otherwise */
+#define NQA_MIXED_STAGES(prec) ((prec) == NQA_PREC_F32M ? 3 : (prec) == NQA_PREC_F32M2 ? 2 : 0)
 
 enum {
   NQA_OK = 0,

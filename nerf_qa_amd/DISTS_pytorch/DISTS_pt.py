@@ -35,12 +35,13 @@ _DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 #   * frames below AUTO_MIN_PIXELS always run in f32s (split-f16 products on float32 activations, <= 1e-6): f16's
 #     |dscore| has a tail above the bar on small frames whose deep-stage statistics run over a handful of pixels
 #     (tools/gpu_stress_small.py: 1 of 800 random frames up to 64x64 at 1.2e-4);
-#   * larger frames run in the FASTEST of three modes that a one-time calibration with these very weights admits:
-#       f16   one MFMA per product, f16 activations and weights                       (~2.7x the throughput of f32s)
-#       f32m  "mixed": stages 1..3 f16 activations x two-term (hi, lo) weights, 2 MFMAs; stages 4..5 as f32s
-#       f32s  float activations, three-term split products, <= 1e-6                  (always admitted)
+#   * larger frames run in the FASTEST of four modes that a one-time calibration with these very weights admits:
+#       f16    one MFMA per product, f16 activations and weights                      (~2.8x the throughput of f32s)
+#       f32m   "mixed": stages 1..3 f16 activations x two-term (hi, lo) weights, 2 MFMAs; stages 4..5 as f32s (~1.4x)
+#       f32m2  the same with only stages 1..2 on two-term weights                     (~1.25x)
+#       f32s   float activations, three-term split products, <= 1e-6                 (always admitted)
 #     The first time it matters, 128 synthetic 128x128 pairs (additive noise at two levels, 5x5 blur, independent
-#     content) go through all three on the GPU (~30 ms); a mode is admitted when rms(score - score_f32s) <=
+#     content) go through all four on the GPU (~40 ms); a mode is admitted when rms(score - score_f32s) <=
 #     AUTO_F16_RMS (2e-5) and max <= AUTO_F16_BUDGET (6e-5).
 # Why a measurement and not a rule: tools/cpu_prec_layers.py shows the 16-bit error is spread evenly over all 13
 # layers and over both operands (weights and activations each ~2.3e-5 rms at stand-in gain 1.6), so no small set of
@@ -173,9 +174,9 @@ class DISTS(torch.nn.Module):
     @torch.no_grad()
     def calibrate(self, device, force: bool = False) -> dict:
         """Measure f16 and f32m against f32s with this module's VGG weights on `device` (once per weight set and
-        device) and decide what `auto` runs frames of >= AUTO_MIN_PIXELS in: the fastest of f16 / f32m / f32s whose
-        deviation from f32s stays inside the budgets.  Returns the report {"choice", "f16": {max_abs_diff, rms_diff,
-        ok}, "f32m": {...}, "budget", "rms_budget", "pairs", "size"}."""
+        device) and decide what `auto` runs frames of >= AUTO_MIN_PIXELS in: the fastest of f16 / f32m / f32m2 / f32s
+        whose deviation from f32s stays inside the budgets.  Returns the report {"choice", "f16": {max_abs_diff,
+        rms_diff, ok}, "f32m": {...}, "f32m2": {...}, "budget", "rms_budget", "pairs", "size"}."""
         device = torch.device(device)
         if device.type != "cuda":
             raise NqaError("precision='auto' calibrates on the GPU: move the module to cuda first "
@@ -192,12 +193,12 @@ class DISTS(torch.nn.Module):
         ab = np.load(_DATA)
         a, b = torch.from_numpy(ab["alpha"]).to(device), torch.from_numpy(ab["beta"]).to(device)
         score = {}
-        for prec in ("f16", "f32m", "f32s"):
+        for prec in ("f16", "f32m", "f32m2", "f32s"):
             s1, s2 = ops.dists_forward(x, y, self._packed_weights(device, prec), prec, ws)
             score[prec] = ops.dists_score(s1, s2, a, b)
         report = {"budget": budget, "rms_budget": rms_budget, "pairs": int(x.shape[0]), "size": int(x.shape[-1])}
         choice = "f32s"
-        for prec in ("f32m", "f16"):  # (the later, faster mode wins if it passes too)
+        for prec in ("f32m2", "f32m", "f16"):  # (the later, faster mode wins if it passes too)
             d = (score[prec] - score["f32s"]).double()
             ok = bool(torch.isfinite(d).all())
             mx = float(d.abs().max()) if ok else float("inf")

@@ -60,7 +60,7 @@ TimedLaunch::~TimedLaunch() {
 // ---- packed weight blob -------------------------------------------------------------
 // bytes per weight in the blob of `prec`: NQA_PREC_F32M holds f16 (hi, lo) pairs for layers 1..6 and f32s rows
 // (also hi + lo halves) for layers 7..12
-static size_t blob_weight_bytes(int prec) { return prec == NQA_PREC_F32M ? 4 : prec_elem_bytes(prec); }
+static size_t blob_weight_bytes(int prec) { return is_mixed(prec) ? 4 : prec_elem_bytes(prec); }
 static size_t layer_bytes(int layer, int prec) {
   const ConvSpec &c = kConvs[layer];
   if (layer == 0) return align_up(27 * 64 * 4 + 64 * 4, 256) + 6144;
@@ -81,7 +81,7 @@ size_t layer0_mfma_offset(int prec) { return layer_offset(0, prec) + align_up(27
 // (NQA_PREC_F32M: the same fragments for 16 channels per group, once as the f16 `hi` and once as the `lo` part of the
 // scaled weights: [cout/16][part][k-steps][64 lanes][8 halfs])
 size_t regw_bytes(int layer, int prec) {
-  return (size_t)kConvs[layer].cout * kConvs[layer].cin * 9 * 2 * (prec == NQA_PREC_F32M ? 2 : 1);
+  return (size_t)kConvs[layer].cout * kConvs[layer].cin * 9 * 2 * (is_mixed(prec) ? 2 : 1);
 }
 static const int kRegwFirst = 1, kRegwLast = 4;  // conv1_2, conv2_1 (Cin 64); conv2_2, conv3_1 (Cin 128)
 // conv1_1 as 16x16x32 MFMA A fragments for conv1_regw_kernel: [4 tiles of 16 channels][2 MFMAs][64 lanes][8 halfs];
@@ -182,7 +182,7 @@ size_t max_act_elems(int H, int W) {
   return m;
 }
 static size_t act_bytes(int n, int H, int W, int prec) {
-  if (prec == NQA_PREC_F32M) {  // the largest map in BYTES: stages differ in element size
+  if (is_mixed(prec)) {  // the largest map in BYTES: stages differ in element size
     static const int kStageC[5] = {64, 128, 256, 512, 512};
     const PyrDims d = pyr_dims(H, W);
     size_t m = 0;
@@ -211,7 +211,7 @@ static int run_stages(const float *x, const float *y, int nx, void *bufA, void *
   const PyrDims d = pyr_dims(H, W);
   void *cur = bufA;
   int rc;
-  if (prec == NQA_PREC_F32M) {
+  if (is_mixed(prec)) {
     // mixed mode: conv1_1 exact in float -> half; layers 1..6 the f16 kernels on two-term weights; the pool behind
     // stage 3 writes split16 records; layers 7..12 the f32s kernels.  on_tap sees the stage's own kernel precision.
     const bool fused_m = W >= 16 && !mixed_stage1_unfused();
@@ -285,7 +285,7 @@ static bool bad_dims(const char *who, int n, int H, int W, int prec, int chan = 
     return true;
   }
   if (!(pyramid ? prec_valid_pyramid(prec) : prec_valid(prec))) {
-    set_error(prec == NQA_PREC_F32M ? "%s: NQA_PREC_F32M (%d) is a mode of the DISTS pyramid entry points only"
+    set_error(is_mixed(prec) ? "%s: NQA_PREC_F32M / F32M2 (%d) is a mode of the DISTS pyramid entry points only"
                                     : "%s: unknown prec %d", who, prec);
     return true;
   }
@@ -380,7 +380,7 @@ int nqa_timing_collect(int launches[NQA_K_COUNT], double ms[NQA_K_COUNT]) {
 size_t nqa_packed_weights_bytes(int prec) {
   if (!prec_valid_pyramid(prec)) return 0;
   size_t n = layer_offset(NQA_NUM_CONVS, prec);
-  if (prec == NQA_PREC_F32M || prec_elem_bytes(prec) == 2) n = layer0_m16_offset(prec) + kW1M16Bytes * (prec == NQA_PREC_F32M ? 2 : 1);
+  if (is_mixed(prec) || prec_elem_bytes(prec) == 2) n = layer0_m16_offset(prec) + kW1M16Bytes * (is_mixed(prec) ? 2 : 1);
   return n;
 }
 
@@ -402,7 +402,7 @@ int nqa_pack_vgg_weights(const float *const w_host[NQA_NUM_CONVS], const float *
       for (int c = 0; c < 3; ++c)
         for (int t = 0; t < 9; ++t) w0[(t * 3 + c) * 64 + co] = w_host[0][(co * 3 + c) * 9 + t];
     memcpy(blob + layer_bias_offset(0, prec), b_host[0], 64 * 4);
-    if (prec != NQA_PREC_F32M && prec_elem_bytes(prec) == 2) {  // MFMA A fragments for the fused stage-1 kernel
+    if (!is_mixed(prec) && prec_elem_bytes(prec) == 2) {  // MFMA A fragments for the fused stage-1 kernel
       uint16_t *wm = reinterpret_cast<uint16_t *>(blob + layer0_mfma_offset(prec));
       for (int ky = 0; ky < 3; ++ky)
         for (int co = 0; co < 64; ++co)
@@ -507,7 +507,7 @@ int nqa_pack_vgg_weights(const float *const w_host[NQA_NUM_CONVS], const float *
             }
     memcpy(blob + layer_bias_offset(l, prec), b_host[l], (size_t)cs.cout * 4);
   }
-  if (prec == NQA_PREC_F32M) {
+  if (is_mixed(prec)) {
     // conv1_1 for conv1_regw_kernel<.., NTERM = 2>: [4 tiles of 16 channels][2 MFMAs][part: hi, lo][64 lanes][8 halfs] of
     // the weights times a power of two; 1 / that scale in the first float of the 32x32-fragment area
     const int k1 = weight_scale_exp(w_host[0], 64 * 27);
@@ -543,7 +543,7 @@ int nqa_pack_vgg_weights(const float *const w_host[NQA_NUM_CONVS], const float *
               }
     }
   }
-  if (prec != NQA_PREC_F32M && prec_elem_bytes(prec) == 2) {
+  if (!is_mixed(prec) && prec_elem_bytes(prec) == 2) {
     for (int l = kRegwFirst; l <= kRegwLast; ++l) {
       const ConvSpec &cs = kConvs[l];
       const int nks = cs.cin / 32 * 9;  // k-steps: chunk * 9 + tap
@@ -708,7 +708,7 @@ int nqa_dists_forward(const float *x, const float *y, int B, int H, int W, const
         double *pk = part + p.d.part_off[k + 1];
         const int kp = stage_prec(prec, k);  // (mixed mode: half taps up to stage 3, float ones behind)
         if (!pool_dst) return stats_nhwc(tap, B, hk * wk, ck, kp, pk, st);
-        const bool boundary = prec == NQA_PREC_F32M && kp == NQA_PREC_F16 && stage_prec(prec, k + 1) == NQA_PREC_F32S;
+        const bool boundary = is_mixed(prec) && kp == NQA_PREC_F16 && stage_prec(prec, k + 1) == NQA_PREC_F32S;
         const int rc2 = boundary ? pool_stats_to_split16(tap, B, hk, wk, ck, pool_dst, pk, st)
                                  : pool_stats(tap, B, hk, wk, ck, kp, pool_dst, pk, st);
         return rc2 ? rc2 : 1;

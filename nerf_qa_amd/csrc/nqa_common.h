@@ -143,11 +143,12 @@ __host__ __device__ static inline size_t prec_elem_bytes(int prec) {
   return prec == NQA_PREC_F32 || prec == NQA_PREC_F32S ? 4 : 2;
 }
 static inline bool prec_valid(int prec) { return prec >= NQA_PREC_F32 && prec <= NQA_PREC_F32S; }  // kernel-level modes
-static inline bool prec_valid_pyramid(int prec) { return prec_valid(prec) || prec == NQA_PREC_F32M; }
+static inline bool is_mixed(int prec) { return NQA_MIXED_STAGES(prec) > 0; }
+static inline bool prec_valid_pyramid(int prec) { return prec_valid(prec) || is_mixed(prec); }
 // the kernel precision of pyramid stage `stage` (0-based) in mode `prec`
 static inline int stage_prec(int prec, int stage) {
-  if (prec != NQA_PREC_F32M) return prec;
-  return stage < NQA_MIXED_STAGES ? NQA_PREC_F16 : NQA_PREC_F32S;
+  if (!is_mixed(prec)) return prec;
+  return stage < NQA_MIXED_STAGES(prec) ? NQA_PREC_F16 : NQA_PREC_F32S;
 }
 // weight terms per product of conv layer `layer` in mode `prec` (2: f16 hi + lo against f16 activations)
 static inline int layer_terms(int prec, int layer);
@@ -164,7 +165,7 @@ static const ConvSpec kConvs[NQA_NUM_CONVS] = {
     {256, 256, 2, 0}, {256, 256, 2, 1}, {256, 512, 3, 0}, {512, 512, 3, 0}, {512, 512, 3, 1},
     {512, 512, 4, 0}, {512, 512, 4, 0}, {512, 512, 4, 1}};
 static inline int layer_terms(int prec, int layer) {
-  return prec == NQA_PREC_F32M && kConvs[layer].stage < NQA_MIXED_STAGES ? 2 : 1;
+  return kConvs[layer].stage < NQA_MIXED_STAGES(prec) ? 2 : 1;
 }
 static const int kChns[NQA_NUM_TAPS] = {3, 64, 128, 256, 512, 512};
 static const int kChnOff[NQA_NUM_TAPS] = {0, 3, 67, 195, 451, 963};

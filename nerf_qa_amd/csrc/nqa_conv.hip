@@ -2168,7 +2168,7 @@ int conv1_1(const float *x, int n, int H, int W, const void *packed, int prec, v
 int conv3x3_blob(const void *in, int n, int H, int W, int layer, const void *packed, int blob_prec, int kprec,
                  void *out, hipStream_t st) {
   const char *p = static_cast<const char *>(packed);
-  if (blob_prec == NQA_PREC_F32M) {
+  if (is_mixed(blob_prec)) {
     if (kprec == NQA_PREC_F16) return launch_conv<PrecF16>(in, n, H, W, layer, p, out, st, blob_prec);
     if (kprec == NQA_PREC_F32S) return launch_conv<PrecF32S>(in, n, H, W, layer, p, out, st, blob_prec);
   }
@@ -2179,7 +2179,7 @@ int conv3x3_blob(const void *in, int n, int H, int W, int layer, const void *pac
 // stage 1 of the mixed mode in one kernel (two-term conv1_1 and conv1_2), images [x(0..B), y(0..n-B))
 int conv1_fused_blob(const float *x, const float *y, int B, int n, int H, int W, const void *packed, int blob_prec,
                      void *out, hipStream_t st) {
-  if (blob_prec != NQA_PREC_F32M) {
+  if (!is_mixed(blob_prec)) {
     set_error("conv1_fused_blob: NQA_PREC_F32M blobs only");
     return NQA_E_ARG;
   }
@@ -2189,7 +2189,7 @@ int conv1_fused_blob(const float *x, const float *y, int B, int n, int H, int W,
 int conv1_1_blob(const float *x, int n, int H, int W, const void *packed, int blob_prec, int kprec, void *out,
                  hipStream_t st) {
   const char *p = static_cast<const char *>(packed);
-  if (blob_prec == NQA_PREC_F32M && kprec == NQA_PREC_F16) return launch_conv1_1<PrecF16>(x, n, H, W, p, out, st, blob_prec);
+  if (is_mixed(blob_prec) && kprec == NQA_PREC_F16) return launch_conv1_1<PrecF16>(x, n, H, W, p, out, st, blob_prec);
   set_error("conv1_1_blob: unsupported blob / kernel precision pair %d / %d", blob_prec, kprec);
   return NQA_E_ARG;
 }

@@ -78,7 +78,7 @@ def test_dists_b32_256_vs_reference(gain, dev):
     print(f"\nDISTS B=32 256x256 gain {gain} DEFAULT (auto -> {rep['choice']}; calibration |f16-f32s| max "
           f"{rep['max_abs_diff']:.2e} rms {rep['rms_diff']:.2e}): max|dscore|={err:.2e}")
     assert err <= 1e-4, ("auto", rep, gain, err)
-    assert rep["choice"] == {1.0: "f16", 1.3: "f32m", 1.6: "f32s"}[gain], rep  # (what the pinned sets are known to measure)
+    assert rep["choice"] == {1.0: "f16", 1.3: "f32m", 1.6: "f32m2"}[gain], rep  # (what the pinned sets are known to measure)
     del m
     # per-channel S1 / S2 are quotients with c = 1e-6: on nearly dead channels (variance ~1e-6) a 1e-9 difference in
     # a moment moves S2 by 1e-3, so they get a loose bound; the score (their alpha/beta-weighted sum) is the bar.
@@ -86,7 +86,7 @@ def test_dists_b32_256_vs_reference(gain, dev):
     # chooses it (gain 1.0); at gains 1.3 / 1.6 it is OUT OF SPEC by construction (heavy-tailed error: this batch
     # lands at 6e-5 / 1e-4, other seeds at 1.3e-4 / 2e-4, tools/gpu_auto_calibration.py) -- that is why auto does not
     # choose it there; the value is printed, not gated (only a sanity bound).
-    for prec, tol, stol in (("f16", 1e-4 if gain == 1.0 else None, None), ("f32m", 4e-5, None), ("f32s", 5e-6, 2e-2),
+    for prec, tol, stol in (("f16", 1e-4 if gain == 1.0 else None, None), ("f32m", 4e-5, None), ("f32m2", 2e-5, None), ("f32s", 5e-6, 2e-2),
                             ("f32", 5e-6, 2e-2)):
         m = DISTS(precision=prec, vgg16_path=_spec(gain)).to(dev).eval()
         with torch.no_grad():
