@@ -65,8 +65,8 @@ WORKLOADS = {
                           "seed = frame index, sharded over the ranks", B=8, H=1080, W=1920, metric="DISTS"),
 }
 # what the N=1 line measures beside the headline (workload key, precision)
-COMPANIONS = (("1080p", "f32m"), ("1080p", "f32s"), ("256", "f16"), ("256", "f32m"), ("256", "f32s"),
-              ("adists1080p", "f32s"))
+COMPANIONS = (("1080p", "f32m"), ("1080p", "f32m2"), ("1080p", "f32s"), ("256", "f16"), ("256", "f32m"),
+              ("256", "f32s"), ("adists1080p", "f32s"))
 PEAK_F16_TFLOPS = 2500.0  # dense f16/bf16 MFMA, MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3   # exact-f32 MFMA
 PEAK_HBM_GBS = 8000.0
@@ -114,16 +114,15 @@ def pool_bytes_per_image(h, w, prec):
 def load_traffic():
     """Committed PMC summary (rocprofv3 --pmc passes of this command, corrected as MI355X_MICROARCH.md's HBM
     section prescribes: FETCH_SIZE doubled on gfx950): {workload/prec: {"conv": bytes per launch, "pool": ...}}.
-    The figures belong to the library build named in the file ("lib_sha16"); the line carries that and whether the
-    library it ran matches, so stale bytes are never shown as fresh ones."""
+    The figures belong to the library SOURCES named in the file ("lib_sha16" = nerf_qa_amd.build.source_hash());
+    when the tree's sources differ the bytes are withheld and the line says why, so stale bytes never pass as fresh."""
     try:
         t = json.load(open(os.path.join(ROOT, TRAFFIC_FILE)))
     except (OSError, ValueError):
         return {}
     try:
-        import hashlib
-        from nerf_qa_amd import _lib
-        t["_lib_matches"] = hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()[:16] == t.get("lib_sha16")
+        from nerf_qa_amd import build as nqa_build
+        t["_lib_matches"] = nqa_build.source_hash() == t.get("lib_sha16") and not os.environ.get("NQA_LIB")
     except OSError:
         t["_lib_matches"] = False
     return t

@@ -57,6 +57,19 @@ def check_no_scratch(res: dict) -> list:
 FILE_FLAGS = {"nqa_adists.hip": ["-fno-slp-vectorize"]}
 
 
+def source_hash() -> str:
+    """sha256 (16 hex digits) over the HIP sources, headers and compile flags: names the library build that the
+    committed rocprofv3 summaries (profiles/r03_traffic.json) were measured on, independently of the machine."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    for path in files + [os.path.join(HERE, "..", "include", "nqa.h")]:
+        h.update(os.path.basename(path).encode())
+        h.update(open(path, "rb").read())
+    h.update(" ".join(FLAGS + sorted(f"{k}:{' '.join(v)}" for k, v in FILE_FLAGS.items())).encode())
+    return h.hexdigest()[:16]
+
+
 def _stale() -> bool:
     if not os.path.exists(LIB):
         return True
