@@ -47,9 +47,21 @@ def parse_resource_remarks(text: str) -> dict:
     return out
 
 
+# Analysed exceptions, bytes per lane: adists_window_lds_kernel<float, C >= 128> keeps one loop-invariant value of its
+# channel-block loop in scratch (one store before the loop, one reload per channel block, none inside the row loop: ISA
+# checked); the alternatives cost occupancy (nqa_adists.hip).  Anything beyond this fails the build.
+SCRATCH_ALLOWED = {"adists_window_lds_kernel": 8}
+
+
 def check_no_scratch(res: dict) -> list:
-    return sorted(f"{name}: {r['scratch']} bytes/lane of scratch ({r.get('vgprs')} VGPRs)" for name, r in res.items()
-                  if r.get("scratch", 0) and any(k in name for k in NO_SCRATCH))
+    bad = []
+    for name, r in res.items():
+        sc = r.get("scratch", 0)
+        if sc and any(k in name for k in NO_SCRATCH):
+            allowed = max([v for k, v in SCRATCH_ALLOWED.items() if k in name] or [0])
+            if sc > allowed:
+                bad.append(f"{name}: {sc} bytes/lane of scratch ({r.get('vgprs')} VGPRs; allowed {allowed})")
+    return sorted(bad)
 
 # nqa_adists.hip: the window kernels' tap arithmetic is written as scalar float FMAs with literal-constant weights
 # (v_fmac_f32 with a 32-bit immediate); the SLP vectorizer would pair them into v_pk_*_f32, which issue at half

@@ -517,13 +517,8 @@ __global__ __launch_bounds__(256, 3) void adists_window_lds_kernel(
   const unsigned row_stride = (unsigned)W * (unsigned)C * (unsigned)SZ;
   const int rd_base = wave * PXB + lane * SZ;  // this lane's tap 0 of image x inside a slot
   float acc_g = 0.f, acc_t = 0.f, acc_s = 0.f;  // lane l: output row oy0 + 64 k + l of the current 64-row group k
-  // C > 64: two of the three row accumulators live in LDS (touched once per output row by one lane, read by flush):
-  // with all three in registers those instances need 170 VGPRs and spill two to scratch -- whose loads and stores
-  // share the vmcnt counter with the counted-vmcnt DMA ring below.  (The LDS has exactly this much room left at
-  // three blocks per CU; C = 64 keeps all three in registers.)
-  constexpr bool ACC_LDS = C > 64;
-  float *const accl = reinterpret_cast<float *>(smem_w + R * ROWB + 4 * 768) + wave * 128 + lane;
-  if constexpr (ACC_LDS) accl[0] = accl[64] = 0.f;
+  // (Moving two of these accumulators to LDS for C > 64 was tried to spare registers: it takes the block's LDS past a
+  // third of the CU's -- 2 blocks per CU instead of 3 -- see profiles/r03_window_ab.txt.)
   for (int cb = 0; cb < C; cb += 64) {
     const int c = cb + lane;
     // a finished group of (up to) 64 output rows leaves the lanes: stored by the first channel block, added to
@@ -532,7 +527,7 @@ __global__ __launch_bounds__(256, 3) void adists_window_lds_kernel(
       const int r = (orow & ~63) + lane;
       if (live_col && r <= orow) {
         const size_t o = ((size_t)b * Ho + oy0 + r) * Wo + ox;
-        float fg = acc_g, ft = ACC_LDS ? accl[0] : acc_t, fs = ACC_LDS ? accl[64] : acc_s;
+        float fg = acc_g, ft = acc_t, fs = acc_s;
         if (cb > 0) {
           fg += gamma[o];
           ft += tw[o];
@@ -543,7 +538,6 @@ __global__ __launch_bounds__(256, 3) void adists_window_lds_kernel(
         sw[o] = fs;
       }
       acc_g = acc_t = acc_s = 0.f;
-      if constexpr (ACC_LDS) accl[0] = accl[64] = 0.f;
     };
     // the channel's three constants live in LDS (re-read per output row at immediate offsets): with them in
     // registers the C > 64 instances need 172 VGPRs, four past the three-waves-per-SIMD limit
@@ -594,13 +588,8 @@ __global__ __launch_bounds__(256, 3) void adists_window_lds_kernel(
         const int orow = rr - (kWin - 1);                                                                          \
         if (lane == (orow & 63)) {                                                                                 \
           acc_g += gs;                                                                                             \
-          if constexpr (ACC_LDS) {                                                                                 \
-            accl[0] += ts;                                                                                         \
-            accl[64] += sss;                                                                                       \
-          } else {                                                                                                 \
-            acc_t += ts;                                                                                           \
-            acc_s += sss;                                                                                          \
-          }                                                                                                        \
+          acc_t += ts;                                                                                             \
+          acc_s += sss;                                                                                            \
         }                                                                                                          \
         if ((orow & 63) == 63 || orow == nout - 1) flush(orow);                                                    \
       }                                                                                                            \
@@ -1102,8 +1091,8 @@ static int launch_window_lanes(const void *fx, const void *fy, int B, int H, int
   // (the opt-in f16 / bf16 modes) measured 20 % slower that way (2-byte LDS reads + conversions) and keep the first form
   if constexpr (sizeof(typename P::T) == 4) {  // (the LDS kernel is instantiated for float taps only)
   if (!adists_window_legacy()) {
-    // four ring slots + the waves' channel constants (3 x 64 floats each) + for C > 64 two row accumulators per lane
-    const int LDS = 4 * 2 * 24 * 64 * 4 + 4 * 768 + (C > 64 ? 4 * 512 : 0);
+    // four ring slots + the waves' channel constants (3 x 64 floats each): 51 KB, three blocks per CU
+    const int LDS = 4 * 2 * 24 * 64 * 4 + 4 * 768;
     // strips as tall as the grid allows (up to 256 rows): the fewest strips that still give the chip ~8 rounds
     // of blocks (3 blocks per CU), else 64-row strips
     const int nbx = cdiv(Wo, 4);
