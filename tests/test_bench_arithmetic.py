@@ -21,8 +21,16 @@ def test_algorithmic_flops_and_bytes_match_the_survey():
     assert abs((ig256 + c1_256) / 1e9 - 40.089) < 0.01
     assert abs((ig1080 + c1_1080) / 1e9 - 1269.295) < 0.05
     # L2-pool row of SURVEY 8(d): 39.3 MB (fp32) per 256x256 image, 1244.3 MB per 1080p image
-    assert abs(b.pool_bytes_per_image(256, 256, 4) / 1e6 - 39.3) < 0.1
-    assert abs(b.pool_bytes_per_image(1080, 1920, 4) / 1e6 - 1244.3) < 0.5
+    assert abs(b.pool_bytes_per_image(256, 256, "f32s") / 1e6 - 39.3) < 0.1
+    assert abs(b.pool_bytes_per_image(1080, 1920, "f32s") / 1e6 - 1244.3) < 0.5
+    assert b.pool_bytes_per_image(1080, 1920, "f16") * 2 == b.pool_bytes_per_image(1080, 1920, "f32")
+    # mixed modes: half taps up to the last two-term stage, whose pool writes 4-byte split16 records
+    f16, f32 = b.pool_bytes_per_image(1080, 1920, "f16"), b.pool_bytes_per_image(1080, 1920, "f32s")
+    assert f16 < b.pool_bytes_per_image(1080, 1920, "f32m") < b.pool_bytes_per_image(1080, 1920, "f32m2") < f32
+    # issued f16-MFMA FLOPs: f32s three per product everywhere, f32m two in layers 1..6, f32m2 two in layers 1..3
+    alg = b.conv_flops_per_image(1080, 1920)[0]
+    assert b.conv_flops_per_image(1080, 1920, "f32s")[0] == 3 * alg and b.conv_flops_per_image(1080, 1920, "f16")[0] == alg
+    assert 2 * alg < b.conv_flops_per_image(1080, 1920, "f32m")[0] < b.conv_flops_per_image(1080, 1920, "f32m2")[0] < 3 * alg
 
 
 def test_workloads_name_the_baseline_configs():
@@ -36,4 +44,9 @@ def test_workloads_name_the_baseline_configs():
 def test_committed_traffic_summary_is_readable():
     b = _bench()
     t = b.load_traffic()
-    assert t == {} or all("conv" in v and "pool" in v for v in t.values())
+    entries = {k: v for k, v in t.items() if isinstance(v, dict)}
+    assert t == {} or (entries and all("conv" in v and "pool" in v for v in entries.values()) and "lib_sha16" in t)
+    # the figures are shown only for the library sources they were measured on, and the line always says where from
+    shown = b.traffic_for(t, "1080p/f16")
+    assert "_source" in shown and (("conv" in shown) == bool(t.get("_lib_matches")))
+    assert b.traffic_for(t, "no/such")["_source"].startswith("none")
