@@ -5,6 +5,7 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <thread>
 #include <vector>
 
 #include "nqa_common.h"
@@ -39,10 +40,25 @@ static thread_local bool g_timing = false;
 static thread_local std::vector<hipEvent_t> g_ev0, g_ev1;
 static thread_local std::vector<int> g_cls;
 static thread_local int g_used = 0;
+// The events are created lazily, up to the high-water mark a thread actually used, and given back when the thread
+// ends -- except on the thread that loaded the library (normally the process's main thread): its thread_locals are
+// destroyed during process exit, when the HIP runtime may already be gone.
+static const std::thread::id g_load_thread = std::this_thread::get_id();
+struct TimingRingOwner {
+  ~TimingRingOwner() {
+    if (std::this_thread::get_id() == g_load_thread) return;
+    for (hipEvent_t e : g_ev0) (void)hipEventDestroy(e);
+    for (hipEvent_t e : g_ev1) (void)hipEventDestroy(e);
+    g_ev0.clear();
+    g_ev1.clear();
+  }
+};
+static thread_local TimingRingOwner g_ring_owner;  // constructed after the vectors (first touched below), destroyed before them
 
 TimedLaunch::TimedLaunch(int kc, hipStream_t s) : kclass(kc), stream(s), slot(-1) {
   if (!g_timing || g_used >= kRing) return;
   if ((int)g_ev0.size() <= g_used) {
+    (void)&g_ring_owner;  // (odr-use: the owner exists in every thread that ever creates events)
     hipEvent_t a, b;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
     g_ev0.push_back(a);

@@ -62,3 +62,36 @@ def test_two_threads_score_concurrently(metric):
     assert len(results) == 4 * len(data)
     for (tid, rep, i), s in results.items():
         assert torch.equal(s, alone[i]), (metric, tid, rep, i, (s - alone[i]).abs().max().item())
+
+
+def test_timing_ring_of_a_worker_thread_is_released_at_thread_exit():
+    """The per-thread timing ring (hipEvent pairs, created lazily) is given back when the thread ends; the main
+    thread's calls before and after are undisturbed and untimed."""
+    import threading
+    from nerf_qa_amd import ops, synth
+    from nerf_qa_amd.DISTS_pytorch import DISTS
+    dev = torch.device("cuda:0")
+    m = DISTS(precision="f32s", vgg16_path="synth:1234").to(dev).eval()
+    xn, yn = synth.frame_batch([1, 2], 48, 64)
+    x, y = torch.from_numpy(xn).to(dev), torch.from_numpy(yn).to(dev)
+    with torch.no_grad():
+        want = m(x, y).clone()
+    seen = {}
+
+    def worker():
+        ops.timing_enable(True)
+        with torch.no_grad():
+            got = m(x, y)
+        torch.cuda.synchronize(dev)
+        seen["kt"] = ops.timing_collect()
+        seen["equal"] = bool(torch.equal(got, want))
+
+    for _ in range(3):  # three generations of threads, each with its own ring
+        t = threading.Thread(target=worker)
+        t.start()
+        t.join()
+        assert seen["equal"] and seen["kt"]["conv_igemm"][0] == 12 and seen["kt"]["conv_igemm"][1] > 0
+    kt = ops.timing_collect()  # this thread never enabled timing
+    assert all(v[0] == 0 for v in kt.values())
+    with torch.no_grad():
+        assert torch.equal(m(x, y), want)
