@@ -164,8 +164,8 @@ def test_adists_b8_256_vs_reference(gain, dev):
     assert err <= 1e-4, (gain, err)
 
 
-@pytest.mark.parametrize("h,w,prec", [(1080, 1920, "f32s"), (1080, 1920, "f16"), (2160, 3840, "f16")],
-                         ids=["1080p_f32s", "1080p_f16", "4k_f16"])
+@pytest.mark.parametrize("h,w,prec", [(1080, 1920, "f32s"), (1080, 1920, "f16"), (1080, 1920, "f32m"), (2160, 3840, "f16")],
+                         ids=["1080p_f32s", "1080p_f16", "1080p_f32m", "4k_f16"])
 def test_forward_once_full_size(h, w, prec, dev):
     """forward_once (DISTS_pt.py:91-103) at sizes whose float taps exceed 2^31 bytes per image: the NCHW export
     has no 32-bit offset limit; values equal the pyramid's own NHWC taps."""
@@ -177,6 +177,7 @@ def test_forward_once_full_size(h, w, prec, dev):
         feats = m.forward_once(x)
         taps = ops.vgg_pyramid(x, m._packed_weights(dev, prec), prec)
     assert feats[0] is x and [f.shape[1] for f in feats] == [3, 64, 128, 256, 512, 512]
+    assert [t.dtype for t in taps] == [torch.float32 if ops.tap_prec(prec, k) in (0, 3) else torch.float16 for k in range(5)]
     for f, t in zip(feats[1:], taps):
         assert f.dtype == torch.float32 and f.shape == (1, t.shape[3], t.shape[1], t.shape[2])
         assert torch.equal(f, t.permute(0, 3, 1, 2).float())
