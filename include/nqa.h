@@ -224,6 +224,27 @@ enum { NQA_K_CONV1 = 0, NQA_K_CONV = 1, NQA_K_POOL = 2, NQA_K_STATS = 3, NQA_K_A
 int nqa_timing_enable(int on);
 int nqa_timing_collect(int launches[NQA_K_COUNT], double ms[NQA_K_COUNT]);
 
+/* ---- backward pass of the DISTS pyramid: DISTS.forward(x, y, require_grad=True), nerf_qa/DISTS_pytorch/DISTS_pt.py:105-108
+ * (the reference runs forward_once WITH autograd there).  nerf_qa_amd/autograd.py drives these per layer; float
+ * precision throughout (three-term split products).  Not on the scoring hot path.
+ *   nqa_pack_conv_split      one 3x3 layer (float32 OIHW host array; cout % 64 == 0, cin % 16 == 0) in the NQA_PREC_F32S row
+ *                            format, zero bias -- e.g. a layer's flipped, transposed weights for its data gradient;
+ *   nqa_conv3x3_split        that layer: split16 NHWC in, FLOAT NHWC out, ReLU optional;
+ *   nqa_relu_mask_split16    g * (act > 0) as split16 records (act: a float tapped map, or split16);
+ *   nqa_l2pool_backward      g_tap += d(L2-pool)/d(tap) applied to g_pooled (DISTS_pt.py:22-25), pooled = the forward's split16 map;
+ *   nqa_conv1_1_backward     g * (relu1_1 > 0) (float NHWC, 64 channels) -> gradient of the RAW image, float NCHW (n,3,H,W),
+ *                            the (x - mean) / std of DISTS_pt.py:92 included; w = conv1_1's float32 OIHW weights on the device. */
+size_t nqa_packed_conv_split_bytes(int cout, int cin);
+int nqa_pack_conv_split(const float *w_oihw, int cout, int cin, void *packed_host);
+int nqa_conv3x3_split(const void *in_split16, int n, int H, int W, int cin, int cout, const void *packed_conv, int relu,
+                      float *out_nhwc, void *stream);
+int nqa_relu_mask_split16(const float *g_nhwc, const void *act_nhwc, int act_is_split16, long pixels, int C,
+                          void *out_split16, void *stream);
+int nqa_l2pool_backward(const float *tap_nhwc, const void *pooled_split16, const float *g_pooled_nhwc, int n, int H, int W,
+                        int C, float *g_tap_nhwc, void *stream);
+int nqa_conv1_1_backward(const float *gm_nhwc, const float *w_oihw_dev, int n, int H, int W, float *g_image_nchw,
+                         void *stream);
+
 #ifdef __cplusplus
 }
 #endif

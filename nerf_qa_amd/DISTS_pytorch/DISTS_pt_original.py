@@ -52,9 +52,7 @@ class DISTS(_BaseDISTS):
         self.beta.data = beta / weight_sum
 
     def forward(self, x, y, require_grad=False, batch_average=False):
-        if require_grad:
-            raise NotImplementedError("require_grad=True needs a backward pass through the VGG pyramid")
-        s1, s2 = self._similarities(x, y)
+        s1, s2 = self._similarities(x, y, require_grad)
         flags = str(config().dists_weight_norm).split("+")
         alpha = torch.relu(self.alpha) if "relu" in flags else self.alpha
         beta = torch.relu(self.beta) if "relu" in flags else self.beta

@@ -36,9 +36,7 @@ class DISTS(_BaseDISTS):
         return self
 
     def forward(self, x, y, require_grad=False, batch_average=False, warp=None, certainty=None):
-        if require_grad:
-            raise NotImplementedError("require_grad=True needs a backward pass through the VGG pyramid")
-        s1, s2 = self._similarities(x, y)
+        s1, s2 = self._similarities(x, y, require_grad)
         w = torch.softmax(torch.cat([self.alpha, self.beta], dim=1), dim=1)
         alpha, beta = torch.split(w, self.alpha.shape[1], dim=1)
         alpha, beta = alpha.view(1, -1), beta.view(1, -1)

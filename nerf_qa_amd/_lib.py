@@ -57,6 +57,12 @@ _SIGNATURES = {
     "nqa_u8_resize_bilinear_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "nqa_resize_pil_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "nqa_resize_pil_bilinear_u8": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp]),
+    "nqa_packed_conv_split_bytes": (_sz, [_i, _i]),
+    "nqa_pack_conv_split": (_i, [_vp, _i, _i, _vp]),
+    "nqa_conv3x3_split": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
+    "nqa_relu_mask_split16": (_i, [_vp, _vp, _i, C.c_long, _i, _vp, _vp]),
+    "nqa_l2pool_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "nqa_conv1_1_backward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "nqa_set_conv_variant": (_i, [_i]),
     "nqa_timing_enable": (_i, [_i]),
     "nqa_timing_collect": (_i, [C.POINTER(_i), C.POINTER(C.c_double)]),

@@ -779,4 +779,85 @@ int nqa_dists_score(const float *s1, const float *s2, const float *alpha, const 
   return score(s1, s2, alpha, beta, B, out, static_cast<hipStream_t>(stream));
 }
 
+
+// ---- backward pass (DISTS require_grad=True; nqa_backward.hip) -----------------------------------------------------
+static size_t conv_split_bias_off(int cout, int cin) { return align_up((size_t)cout * cin * 9 * 4, 256); }
+
+size_t nqa_packed_conv_split_bytes(int cout, int cin) {
+  if (cout <= 0 || cin <= 0 || cout % 64 || cin % 16) return 0;
+  return conv_split_bias_off(cout, cin) + align_up((size_t)cout * 4 + 4, 256);
+}
+
+int nqa_pack_conv_split(const float *w_oihw, int cout, int cin, void *packed_host) {
+  if (!w_oihw || !packed_host || cout <= 0 || cin <= 0 || cout % 64 || cin % 16) {
+    set_error("pack_conv_split: bad argument (cout %d must be a multiple of 64, cin %d of 16)", cout, cin);
+    return NQA_E_ARG;
+  }
+  char *blob = static_cast<char *>(packed_host);
+  memset(blob, 0, nqa_packed_conv_split_bytes(cout, cin));  // (bias = 0)
+  const int k = weight_scale_exp(w_oihw, (size_t)cout * cin * 9);
+  const float wscale = ldexpf(1.f, k), winv = ldexpf(1.f, -k);
+  memcpy(blob + conv_split_bias_off(cout, cin) + (size_t)cout * 4, &winv, 4);
+  const int bn = 64, ncc = cin / 16;  // the f32s row layout of nqa_pack_vgg_weights
+  for (int ct = 0; ct < cout / bn; ++ct)
+    for (int cc = 0; cc < ncc; ++cc)
+      for (int t = 0; t < 9; ++t)
+        for (int n = 0; n < bn; ++n)
+          for (int pos = 0; pos < 4; ++pos) {
+            const int c = pos ^ ((n >> 2) & 3);
+            uint16_t *row = reinterpret_cast<uint16_t *>(blob) + (((((size_t)ct * ncc + cc) * 9 + t) * bn + n) * 4 + pos) * 8;
+            for (int j = 0; j < 8; ++j) {
+              const int ci = cc * 16 + (c & 1) * 8 + j, co = ct * bn + n;
+              const float v = w_oihw[((size_t)co * cin + ci) * 9 + t] * wscale;
+              const uint16_t hi = f32_to_f16(v);
+              row[j] = c < 2 ? hi : f32_to_f16(v - f16_to_f32(hi));
+            }
+          }
+  return NQA_OK;
+}
+
+int nqa_conv3x3_split(const void *in_split16, int n, int H, int W, int cin, int cout, const void *packed_conv, int relu,
+                      float *out_nhwc, void *stream) {
+  if (!in_split16 || !packed_conv || !out_nhwc) {
+    set_error("conv3x3_split: null pointer");
+    return NQA_E_ARG;
+  }
+  if (cout <= 0 || cin <= 0 || cout % 64 || cin % 16) {
+    set_error("conv3x3_split: cout %d must be a multiple of 64, cin %d of 16", cout, cin);
+    return NQA_E_SHAPE;
+  }
+  if (bad_dims("conv3x3_split", n, H, W, NQA_PREC_F32S, cin > cout ? cin : cout)) return NQA_E_ARG;
+  return conv3x3_split_generic(in_split16, n, H, W, cin, cout, packed_conv, conv_split_bias_off(cout, cin), relu,
+                               out_nhwc, static_cast<hipStream_t>(stream));
+}
+
+int nqa_relu_mask_split16(const float *g_nhwc, const void *act_nhwc, int act_is_split16, long pixels, int C,
+                          void *out_split16, void *stream) {
+  if (!g_nhwc || !act_nhwc || !out_split16 || pixels <= 0 || C <= 0 || C % 16) {
+    set_error("relu_mask_split16: bad argument (C %d must be a positive multiple of 16)", C);
+    return NQA_E_ARG;
+  }
+  return relu_mask_split16(g_nhwc, act_nhwc, act_is_split16, pixels, C, out_split16, static_cast<hipStream_t>(stream));
+}
+
+int nqa_l2pool_backward(const float *tap_nhwc, const void *pooled_split16, const float *g_pooled_nhwc, int n, int H, int W,
+                        int C, float *g_tap_nhwc, void *stream) {
+  if (!tap_nhwc || !pooled_split16 || !g_pooled_nhwc || !g_tap_nhwc || C <= 0 || C % 16) {
+    set_error("l2pool_backward: bad argument");
+    return NQA_E_ARG;
+  }
+  if (bad_dims("l2pool_backward", n, H, W, NQA_PREC_F32, 0)) return NQA_E_ARG;
+  return l2pool_backward(tap_nhwc, pooled_split16, g_pooled_nhwc, n, H, W, C, g_tap_nhwc, static_cast<hipStream_t>(stream));
+}
+
+int nqa_conv1_1_backward(const float *gm_nhwc, const float *w_oihw_dev, int n, int H, int W, float *g_image_nchw,
+                         void *stream) {
+  if (!gm_nhwc || !w_oihw_dev || !g_image_nchw) {
+    set_error("conv1_1_backward: null pointer");
+    return NQA_E_ARG;
+  }
+  if (bad_dims("conv1_1_backward", n, H, W, NQA_PREC_F32, 0)) return NQA_E_ARG;
+  return conv1_1_backward(gm_nhwc, w_oihw_dev, n, H, W, g_image_nchw, static_cast<hipStream_t>(stream));
+}
+
 }  // extern "C"

@@ -219,6 +219,12 @@ int conv1_1_blob(const float *x, int n, int H, int W, const void *packed, int bl
 int conv1_fused_blob(const float *x, const float *y, int B, int n, int H, int W, const void *packed, int blob_prec,
                      void *out, hipStream_t st);
 bool mixed_stage1_unfused();  // (A/B switch of nqa_set_conv_variant's first-forms bit)
+int relu_mask_split16(const float *g, const void *act, int act_split, long npix, int C, void *out, hipStream_t st);
+int l2pool_backward(const float *x, const void *y_split16, const float *gy, int n, int H, int W, int C, float *gx,
+                    hipStream_t st);
+int conv1_1_backward(const float *gm, const float *w_oihw, int n, int H, int W, float *gimg, hipStream_t st);
+int conv3x3_split_generic(const void *in, int n, int H, int W, int cin, int cout, const void *blob, size_t bias_off,
+                          int relu, void *out, hipStream_t st);
 int l2pool_to_split16(const void *in_f16, int n, int H, int W, int C, void *out_split16, hipStream_t st);
 int pool_stats_to_split16(const void *feat_f16, int B, int H, int W, int C, void *pooled_split16, double *part,
                           hipStream_t st);

@@ -189,7 +189,7 @@ __host__ __device__ inline int lds_swz(int r) {
 template <typename P, int WAVES_N, int WAVES_M, int WN_T, int WM_T, int TW, bool M16, int NTERM = 1>
 __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void conv3x3_igemm_kernel(
     const typename P::T *__restrict__ in, const char *__restrict__ wpk, const float *__restrict__ bias,
-    typename P::T *__restrict__ out, int H, int W, int Cin, int Cout, int tiles_x, int out_split) {
+    typename P::T *__restrict__ out, int H, int W, int Cin, int Cout, int tiles_x, int out_split, float floor_v) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the LDS-DMA builtin exists in the device pass only
   typedef typename P::T T;
   typedef ConvGeom<WAVES_N, WAVES_M, WN_T, WM_T, TW> G;
@@ -509,8 +509,9 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void conv3x3_igemm_kernel(
       a2 *= winv;
       a3 *= winv;
     }
-    const float v[4] = {fmaxf(a0 + b4[0], 0.f), fmaxf(a1 + b4[1], 0.f), fmaxf(a2 + b4[2], 0.f),
-                        fmaxf(a3 + b4[3], 0.f)};
+    // floor_v = 0: the layer's ReLU; -inf: none (the data-gradient convolutions of nqa_backward.hip)
+    const float v[4] = {fmaxf(a0 + b4[0], floor_v), fmaxf(a1 + b4[1], floor_v), fmaxf(a2 + b4[2], floor_v),
+                        fmaxf(a3 + b4[3], floor_v)};
     if constexpr (sizeof(T) == 4) {
       if (P::SPLIT && out_split) {  // feeds another conv: split16 record (wave-uniform branch)
         typedef __attribute__((ext_vector_type(4))) _Float16 h4;
@@ -1853,7 +1854,7 @@ static int launch_conv1_1(const float *x, int n, int H, int W, const char *packe
 
 template <typename P, int WAVES_N, int WAVES_M, int WN_T, int WM_T, int TW, bool M16 = (sizeof(typename P::T) == 2), int NTERM = 1>
 static int launch_igemm(const void *in, int n, int H, int W, int cin, int cout, const char *wpk, const float *bias,
-                        void *out, int out_split, hipStream_t st) {
+                        void *out, int out_split, hipStream_t st, float floor_v = 0.f) {
   typedef ConvGeom<WAVES_N, WAVES_M, WN_T, WM_T, TW> G;
   static std::atomic<bool> attr_done_dev[64];  // the attribute is per device: a process may drive several
   std::atomic<bool> &attr_done = attr_done_dev[current_device() & 63];
@@ -1870,7 +1871,7 @@ static int launch_igemm(const void *in, int n, int H, int W, int cin, int cout, 
   TimedLaunch t(NQA_K_CONV, st);
   conv3x3_igemm_kernel<P, WAVES_N, WAVES_M, WN_T, WM_T, TW, M16, NTERM><<<grid, G::THREADS, G::LDS_BYTES, st>>>(
       reinterpret_cast<const typename P::T *>(in), wpk, bias, reinterpret_cast<typename P::T *>(out), H, W, cin, cout,
-      tiles_x, out_split);
+      tiles_x, out_split, floor_v);
   return check_launch("conv3x3_igemm");
 }
 
@@ -2184,6 +2185,24 @@ int conv1_fused_blob(const float *x, const float *y, int B, int n, int H, int W,
     return NQA_E_ARG;
   }
   return launch_conv1_regw<PrecF16, 2>(x, y, B, n, H, W, static_cast<const char *>(packed), out, st, blob_prec);
+}
+
+// A 3x3 convolution that is not a VGG layer of the packed blob: split16 activations in, FLOAT out, weights as one
+// f32s-format layer blob (rows + bias + 1/scale, nqa_pack_conv_split), ReLU optional.  Used by the backward pass
+// (nqa_backward.hip): the data gradient of a conv layer is the conv of the masked output gradient with the layer's
+// flipped, transposed weights -- Cin' = Cout, Cout' = Cin -- without bias or ReLU.
+int conv3x3_split_generic(const void *in, int n, int H, int W, int cin, int cout, const void *blob, size_t bias_off,
+                          int relu, void *out, hipStream_t st) {
+  const char *wpk = static_cast<const char *>(blob);
+  const float *bias = reinterpret_cast<const float *>(wpk + bias_off);
+  const float fl = relu ? 0.f : -INFINITY;
+  const bool narrow = W <= 16;
+  if (cout % 128 == 0) {
+    return narrow ? launch_igemm<PrecF32S, 2, 2, 2, 2, 16>(in, n, H, W, cin, cout, wpk, bias, out, 0, st, fl)
+                  : launch_igemm<PrecF32S, 2, 2, 2, 2, 32>(in, n, H, W, cin, cout, wpk, bias, out, 0, st, fl);
+  }
+  return narrow ? launch_igemm<PrecF32S, 1, 4, 2, 2, 16, false>(in, n, H, W, cin, cout, wpk, bias, out, 0, st, fl)
+                : launch_igemm<PrecF32S, 1, 4, 2, 2, 32, false>(in, n, H, W, cin, cout, wpk, bias, out, 0, st, fl);
 }
 
 int conv1_1_blob(const float *x, int n, int H, int W, const void *packed, int blob_prec, int kprec, void *out,

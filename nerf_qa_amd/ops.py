@@ -374,3 +374,60 @@ def split16_decode(a: torch.Tensor) -> torch.Tensor:
     out = torch.empty_like(a)
     _call(dev, lib().nqa_split16_decode, ptr(a), a.numel() // c, c, ptr(out), stream_ptr(dev))
     return out
+
+
+# ---- backward pass of the DISTS pyramid (require_grad=True; include/nqa.h, nqa_backward.hip) -----------------------
+def pack_conv_split(w) -> torch.Tensor:
+    """One 3x3 layer (float32 OIHW, cout % 64 == 0, cin % 16 == 0) in the f32s row format, zero bias -> CPU uint8 blob."""
+    w = np.ascontiguousarray(w.detach().cpu().numpy() if torch.is_tensor(w) else w, dtype=np.float32)
+    cout, cin = int(w.shape[0]), int(w.shape[1])
+    assert w.shape[2:] == (3, 3)
+    nbytes = lib().nqa_packed_conv_split_bytes(cout, cin)
+    if not nbytes:
+        raise ValueError(f"pack_conv_split: unsupported layer shape {w.shape}")
+    blob = torch.empty(nbytes, dtype=torch.uint8)
+    check(lib().nqa_pack_conv_split(w.ctypes.data, cout, cin, blob.data_ptr()))
+    return blob
+
+
+def conv3x3_split(inp: torch.Tensor, blob: torch.Tensor, cout: int, relu: bool = False) -> torch.Tensor:
+    """split16 NHWC (n,H,W,cin) -> float32 NHWC (n,H,W,cout) through a layer packed by pack_conv_split."""
+    dev = _need_cuda(inp, blob)
+    assert inp.dtype == torch.float32 and inp.is_contiguous()
+    n, h, w, cin = inp.shape
+    out = torch.empty((n, h, w, cout), dtype=torch.float32, device=dev)
+    _call(dev, lib().nqa_conv3x3_split, ptr(inp), n, h, w, cin, cout, ptr(blob), int(relu), ptr(out), stream_ptr(dev))
+    return out
+
+
+def relu_mask_split16(g: torch.Tensor, act: torch.Tensor, act_is_split16: bool) -> torch.Tensor:
+    """g * (act > 0) as split16 records (float32-typed tensor of g's shape); act: float map or split16 records."""
+    dev = _need_cuda(g, act)
+    g = _f32c(g)
+    assert act.dtype == torch.float32 and act.is_contiguous() and act.shape == g.shape
+    c = g.shape[-1]
+    out = torch.empty_like(g)
+    _call(dev, lib().nqa_relu_mask_split16, ptr(g), ptr(act), int(act_is_split16), g.numel() // c, c, ptr(out),
+          stream_ptr(dev))
+    return out
+
+
+def l2pool_backward(tap: torch.Tensor, pooled_split16: torch.Tensor, g_pooled: torch.Tensor, g_tap: torch.Tensor) -> None:
+    """g_tap += d(L2-pool)/d(tap) applied to g_pooled; tap, g_tap float (n,H,W,C); pooled_split16, g_pooled (n,Ho,Wo,C)."""
+    dev = _need_cuda(tap, pooled_split16, g_pooled, g_tap)
+    n, h, w, c = tap.shape
+    assert g_tap.shape == tap.shape and g_tap.is_contiguous() and tap.is_contiguous() and tap.dtype == torch.float32
+    assert g_pooled.shape == pooled_split16.shape == (n, (h + 1) // 2, (w + 1) // 2, c)
+    _call(dev, lib().nqa_l2pool_backward, ptr(tap), ptr(pooled_split16), ptr(_f32c(g_pooled)), n, h, w, c, ptr(g_tap),
+          stream_ptr(dev))
+
+
+def conv1_1_backward(gm: torch.Tensor, w0: torch.Tensor) -> torch.Tensor:
+    """g * (relu1_1 > 0), float NHWC (n,H,W,64) -> gradient of the raw image, float NCHW (n,3,H,W); w0: conv1_1's OIHW weights."""
+    dev = _need_cuda(gm, w0)
+    gm, w0 = _f32c(gm), _f32c(w0)
+    n, h, w, c = gm.shape
+    assert c == 64 and tuple(w0.shape) == (64, 3, 3, 3)
+    out = torch.empty((n, 3, h, w), dtype=torch.float32, device=dev)
+    _call(dev, lib().nqa_conv1_1_backward, ptr(gm), ptr(w0), n, h, w, ptr(out), stream_ptr(dev))
+    return out

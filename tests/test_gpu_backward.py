@@ -1,0 +1,127 @@
+"""DISTS.forward(x, y, require_grad=True): image gradients through the HIP pyramid (nerf_qa_amd/autograd.py,
+csrc/nqa_backward.hip) against torch autograd over the CPU oracle -- which is what the reference does
+(DISTS_pt.py:105-108 runs forward_once with autograd).  Each backward kernel is also checked on its own."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _oracle_score(x, y, convs, alpha, beta):
+    from oracle import dists_oracle as do
+    f0, f1 = do.vgg_pyramid(x, convs), do.vgg_pyramid(y, convs)
+    s1, s2 = do.dists_stats(f0, f1)
+    return do.dists_score(s1, s2, alpha, beta)
+
+
+@pytest.mark.parametrize("cin,cout,h,w", [(64, 64, 9, 21), (128, 64, 12, 33), (256, 128, 7, 16), (512, 512, 5, 9)])
+def test_conv3x3_split_generic_is_a_float_conv(cin, cout, h, w, dev):
+    from nerf_qa_amd import ops
+    g = torch.Generator().manual_seed(cin + cout)
+    wgt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    a = torch.randn(2, h, w, cin, generator=g)  # signed input, no ReLU anywhere
+    want = F.conv2d(a.permute(0, 3, 1, 2).double(), wgt.double(), padding=1).permute(0, 2, 3, 1).float()
+    blob = ops.pack_conv_split(wgt).to(dev)
+    got = ops.conv3x3_split(ops.split16_encode(a.to(dev)), blob, cout, relu=False).cpu()
+    err = (got - want).abs().max().item() / want.abs().max().item()
+    assert got.min().item() < 0 and err < 2e-6, err
+    got_r = ops.conv3x3_split(ops.split16_encode(a.to(dev)), blob, cout, relu=True).cpu()
+    assert torch.equal(got_r, got.clamp_min(0))
+
+
+def test_relu_mask_l2pool_and_conv1_1_backward_kernels(dev):
+    from nerf_qa_amd import ops
+    from oracle import dists_oracle as do
+    g = torch.Generator().manual_seed(7)
+    # relu mask: float and split16 activations
+    act = torch.randn(2, 5, 9, 64, generator=g).clamp_min(0)
+    gr = torch.randn(2, 5, 9, 64, generator=g)
+    want = gr * (act > 0)
+    for split in (False, True):
+        a_dev = ops.split16_encode(act.to(dev)) if split else act.to(dev)
+        got = ops.split16_decode(ops.relu_mask_split16(gr.to(dev), a_dev, split)).cpu()
+        assert (got - want).abs().max().item() <= 2e-6 * gr.abs().max().item()
+    # L2-pool gradient vs autograd of the oracle's pool, odd sizes (ragged last row / column)
+    for (n, h, w, c) in ((2, 9, 13, 64), (1, 8, 6, 128), (1, 1, 1, 64), (1, 2, 3, 64)):
+        x = (torch.rand(n, c, h, w, generator=g) + 0.05).requires_grad_()
+        yp = do.l2pool(x)
+        gy = torch.randn(yp.shape, generator=g)
+        (yp * gy).sum().backward()
+        tap = x.detach().permute(0, 2, 3, 1).contiguous().to(dev)
+        pooled = ops.l2pool(tap, "f32s")  # split16, as the forward leaves it
+        gt = torch.zeros_like(tap)
+        ops.l2pool_backward(tap, pooled, gy.permute(0, 2, 3, 1).contiguous().to(dev), gt)
+        err = (gt.cpu().permute(0, 3, 1, 2) - x.grad).abs().max().item() / x.grad.abs().max().item()
+        assert err < 1e-5, ((n, h, w, c), err)
+    # conv1_1 gradient (normalisation included) vs autograd
+    w0 = torch.randn(64, 3, 3, 3, generator=g) * 0.2
+    img = torch.rand(2, 3, 7, 10, generator=g).requires_grad_()
+    mean = torch.tensor(do.IMAGENET_MEAN).view(1, 3, 1, 1)
+    std = torch.tensor(do.IMAGENET_STD).view(1, 3, 1, 1)
+    out = F.conv2d((img - mean) / std, w0, padding=1)
+    gm = torch.randn(out.shape, generator=g)
+    (out * gm).sum().backward()
+    got = ops.conv1_1_backward(gm.permute(0, 2, 3, 1).contiguous().to(dev), w0.to(dev)).cpu()
+    assert (got - img.grad).abs().max().item() / img.grad.abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("h,w,kinds", [(40, 56, ("noise10", "blur")), (33, 47, ("indep", "noise02")), (96, 112, ("blur", "noise10"))],
+                         ids=["40x56", "33x47_ragged", "96x112"])
+def test_image_gradients_match_autograd_over_the_oracle(h, w, kinds, dev, oracle_convs):
+    from nerf_qa_amd import synth
+    from nerf_qa_amd.DISTS_pytorch import DISTS
+    m = DISTS(vgg16_path="synth:1234").to(dev).eval()
+    xn, yn = synth.frame_batch([11, 12], h, w, list(kinds))
+    alpha, beta = m.alpha.detach().cpu(), m.beta.detach().cpu()
+    xc, yc = torch.from_numpy(xn).requires_grad_(), torch.from_numpy(yn).requires_grad_()
+    wsum = torch.tensor([1.0, 0.5])  # unequal weights on the two pairs
+    ref = _oracle_score(xc, yc, oracle_convs, alpha, beta)
+    (ref * wsum).sum().backward()
+    xd, yd = torch.from_numpy(xn).to(dev).requires_grad_(), torch.from_numpy(yn).to(dev).requires_grad_()
+    got = m(xd, yd, require_grad=True)
+    assert got.requires_grad and (got.detach().cpu() - ref.detach()).abs().max().item() <= 1e-5
+    (got * wsum.to(dev)).sum().backward()
+    for name, gd, gc in (("x", xd.grad, xc.grad), ("y", yd.grad, yc.grad)):
+        scale = gc.abs().max().item()
+        d = (gd.cpu() - gc)
+        err, rms = d.abs().max().item() / scale, d.pow(2).mean().sqrt().item() / gc.pow(2).mean().sqrt().item()
+        cos = F.cosine_similarity(gd.cpu().flatten(), gc.flatten(), dim=0).item()
+        print(f"\n{h}x{w} d/d{name}: max|grad| {scale:.3e}  max err / max {err:.2e}  rms err / rms {rms:.2e}  cosine {cos:.8f}")
+        # a ReLU whose pre-activation is within rounding of zero may switch sides between two float32 evaluations (the
+        # reference's own autograd has the same edge against float64): isolated pixels, hence the looser max bound
+        assert err <= 2e-2 and rms <= 3e-3 and cos >= 0.99999, (name, err, rms, cos)
+
+
+def test_gradient_only_where_asked_and_with_alpha_beta(dev, oracle_convs):
+    """y without grad: only x gets one; alpha/beta (the fine-tuning parameters) get theirs in the same backward;
+    without require_grad=True nothing reaches the images (DISTS_pt.py:109-111 runs under no_grad)."""
+    from nerf_qa_amd import synth
+    from nerf_qa_amd.DISTS_pytorch.DISTS_pt_original import DISTS
+    m = DISTS(vgg16_path="synth:1234").to(dev)
+    m.alpha.requires_grad_(True)
+    m.beta.requires_grad_(True)
+    xn, yn = synth.frame_batch([3], 48, 40)
+    xd = torch.from_numpy(xn).to(dev).requires_grad_()
+    yd = torch.from_numpy(yn).to(dev)
+    s = m(xd, yd, require_grad=True)  # (0-d for B = 1 in this variant)
+    s.backward()
+    assert xd.grad is not None and xd.grad.abs().max().item() > 0 and yd.grad is None
+    assert m.alpha.grad is not None and m.alpha.grad.abs().max().item() > 0
+    # the oracle's image gradient for the same pair (canonical weighted sum == this variant's with default config)
+    xc = torch.from_numpy(xn).requires_grad_()
+    ref = _oracle_score(xc, torch.from_numpy(yn), oracle_convs, m.alpha.detach().cpu(), m.beta.detach().cpu())
+    ref.sum().backward()
+    assert (xd.grad.cpu() - xc.grad).abs().max().item() <= 1e-2 * xc.grad.abs().max().item()
+    assert F.cosine_similarity(xd.grad.cpu().flatten(), xc.grad.flatten(), dim=0).item() >= 0.99999
+    x2 = torch.from_numpy(xn).to(dev).requires_grad_()
+    s2 = m(x2, yd)  # require_grad=False: value only
+    s2.backward()
+    assert x2.grad is None and abs(s2.item() - s.item()) <= 1e-4

@@ -67,8 +67,8 @@ def test_dists_b32_256_vs_reference(gain, dev):
     x, y = _pairs(g, dev)
     assert x.shape[0] == 32
     # THE GATE: the shipped default ("auto") within 1e-4 of the reference on every pinned weight set.  auto calibrates
-    # f16 against f32s once with the weights at hand (DISTS_pt.py header): gain 1.0 runs in f16, the gains whose
-    # activations grow faster with depth measure above the budget (rms 2e-5 / max 6e-5 on 128 pairs) and run in f32s.
+    # f16 / f32m / f32m2 against f32s once with the weights at hand (DISTS_pt.py header, 384 pairs): gain 1.0 runs in
+    # f32m (f16 measures 6.5e-5 with an outlier tail: refused), gain 1.3 in f32m2, gain 1.6 in f32s.
     m = DISTS(vgg16_path=_spec(gain)).to(dev).eval()
     assert m.precision == "auto"
     rep = m.calibrate(dev)
@@ -78,12 +78,12 @@ def test_dists_b32_256_vs_reference(gain, dev):
     print(f"\nDISTS B=32 256x256 gain {gain} DEFAULT (auto -> {rep['choice']}; calibration |f16-f32s| max "
           f"{rep['max_abs_diff']:.2e} rms {rep['rms_diff']:.2e}): max|dscore|={err:.2e}")
     assert err <= 1e-4, ("auto", rep, gain, err)
-    assert rep["choice"] == {1.0: "f16", 1.3: "f32m", 1.6: "f32m2"}[gain], rep  # (what the pinned sets are known to measure)
+    assert rep["choice"] == {1.0: "f32m", 1.3: "f32m2", 1.6: "f32s"}[gain], rep  # (what the pinned sets are known to measure)
     del m
     # per-channel S1 / S2 are quotients with c = 1e-6: on nearly dead channels (variance ~1e-6) a 1e-9 difference in
     # a moment moves S2 by 1e-3, so they get a loose bound; the score (their alpha/beta-weighted sum) is the bar.
-    # Explicitly named modes: f32s / f32 to 5e-6.  Forced f16 (opt-in fast mode) is held to 1e-4 where auto would
-    # chooses it (gain 1.0); at gains 1.3 / 1.6 it is OUT OF SPEC by construction (heavy-tailed error: this batch
+    # Explicitly named modes: f32s / f32 to 5e-6.  Forced f16 (the opt-in fast mode, which auto admits for NONE of the
+    # three pinned sets) is held to 1e-4 on this batch at gain 1.0; at gains 1.3 / 1.6 it is OUT OF SPEC by construction (heavy-tailed error: this batch
     # lands at 6e-5 / 1e-4, other seeds at 1.3e-4 / 2e-4, tools/gpu_auto_calibration.py) -- that is why auto does not
     # choose it there; the value is printed, not gated (only a sanity bound).
     for prec, tol, stol in (("f16", 1e-4 if gain == 1.0 else None, None), ("f32m", 4e-5, None), ("f32m2", 2e-5, None), ("f32s", 5e-6, 2e-2),

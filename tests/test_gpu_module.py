@@ -104,8 +104,10 @@ def test_refuses_cpu_and_require_grad(model, dev):
     x, y = _pair(32, 32, seeds=(1,))
     with pytest.raises(NqaError):
         model(x, y)
-    with pytest.raises(NotImplementedError):
-        model(x.to(dev), y.to(dev), require_grad=True)
+    # require_grad=True on inputs that carry no gradient: the value, as the reference returns it (DISTS_pt.py:106-108);
+    # the gradient path itself is tests/test_gpu_backward.py
+    with torch.no_grad():
+        assert torch.equal(model(x.to(dev), y.to(dev), require_grad=True), model(x.to(dev), y.to(dev)))
     with pytest.raises(ValueError):
         model(x.to(dev), y[:, :, :16].to(dev))
 
