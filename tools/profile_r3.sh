@@ -14,10 +14,11 @@ run_trace() {  # tag, bench args...
   echo "trace $tag done" >> $R/gpurun_out/prof_r3.progress
 }
 if [ "$WHAT" != "pmc" ]; then
-  run_trace 1080p_f16 --steps 10 --warmup 3
+  run_trace 1080p_auto --steps 6 --warmup 2              # the shipped default (calibrates; f32m on the stand-in weights)
+  run_trace 1080p_f16 --steps 10 --warmup 3 --precision f16
   run_trace 1080p_f32m --steps 6 --warmup 2 --precision f32m
   run_trace 1080p_f32s --steps 5 --warmup 2 --precision f32s
-  run_trace 256_f16 --workload 256 --steps 20 --warmup 3
+  run_trace 256_f16 --workload 256 --steps 20 --warmup 3 --precision f16
   run_trace 256_f32m --workload 256 --steps 10 --warmup 3 --precision f32m
   run_trace adists1080p_f32s --workload adists1080p --steps 5 --warmup 2
 fi
