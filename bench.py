@@ -67,13 +67,15 @@ WORKLOADS = {
                           "seed = frame index, sharded over the ranks", B=8, H=1080, W=1920, metric="DISTS"),
 }
 # what the N=1 line measures beside the headline (workload key, precision)
-COMPANIONS = (("1080p", "f16"), ("1080p", "f32m"), ("1080p", "f32m2"), ("1080p", "f32s"), ("256", "f16"), ("256", "f32m"),
-              ("256", "f32s"), ("adists1080p", "f32s"))  # (the one the headline itself ran in is skipped)
+COMPANIONS = (("1080p", "f16"), ("1080p", "f16w"), ("1080p", "f32m"), ("1080p", "f32m2"), ("1080p", "f32s"),
+              ("256", "f16"), ("256", "f16w"), ("256", "f32m"), ("256", "f32s"),
+              ("adists1080p", "f32s"))  # (the one the headline itself ran in is skipped)
 PEAK_F16_TFLOPS = 2500.0  # dense f16/bf16 MFMA, MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3   # exact-f32 MFMA
 PEAK_HBM_GBS = 8000.0
 MFMA_PER_PRODUCT = {"f16": 1, "bf16": 1, "f32s": 3, "f32": 1}  # f32m: 2 for conv layers 1..6, 3 for 7..12
-MIXED_LAST_2TERM_LAYER = {"f32m": 6, "f32m2": 3}
+MIXED_LAST_2TERM_LAYER = {"f32m": 6, "f32m2": 3, "f32m4": 9, "f16w": 12}
+MIXED_STAGES = {"f32m": 3, "f32m2": 2, "f32m4": 4, "f16w": 5}
 TRAFFIC_FILE = "profiles/r03_traffic.json"
 AUTO_REPORT = {}  # DISTS' one-time precision calibration (what `auto`, the shipped default, chose and on what evidence)
 
@@ -93,8 +95,8 @@ def conv_flops_per_image(h, w, prec=None):
 
 def tap_elem_bytes(prec, k):
     """(bytes per element of tapped map k+1, bytes per element of its pooled map) in mode `prec`."""
-    if prec in ("f32m", "f32m2"):  # half taps 1..3 | 1..2 (the pool behind the last one writes split16 records), float behind
-        ms = 3 if prec == "f32m" else 2
+    if prec in MIXED_STAGES:  # half taps up to the last two-term stage (whose pool writes split16 records), float behind
+        ms = MIXED_STAGES[prec]
         return (2, 2 if k < ms - 1 else 4) if k < ms else (4, 4)
     e = 2 if prec in ("f16", "bf16") else 4
     return e, e
@@ -165,7 +167,7 @@ def rooflines(ktimes, h, w, b, prec, traffic):
         "note": "achieved = algorithmic FLOPs / HIP-event time; peak = dense f16 MFMA (2.5 PF)" if prec != "f32" else
                 "exact-f32 MFMA; peak = 157.3 TF",
     }
-    if prec in ("f32s", "f32m", "f32m2") and ach:
+    if (prec == "f32s" or prec in MIXED_STAGES) and ach:
         issued = ach * issued_flops / ig_flops
         roof["mfma_issued_tflops"] = round(issued, 1)
         roof["frac_of_issued_mfma"] = round(issued / peak, 4)

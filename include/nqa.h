@@ -56,10 +56,14 @@ extern "C" {
  * first seven layers, whose contribution to a DISTS score is the smallest of all (tools/cpu_prec_layers.py).
  *
  * NQA_PREC_F32M2: the same with only stages 1..2 (conv layers 0..3) on two-term weights and stages 3..5 as
- * NQA_PREC_F32S (taps 1..2 half, 3..5 float): 2.6 times less of that residual error for ~10 % of the speed. */
-enum { NQA_PREC_F32 = 0, NQA_PREC_BF16 = 1, NQA_PREC_F16 = 2, NQA_PREC_F32S = 3, NQA_PREC_F32M = 4, NQA_PREC_F32M2 = 5 };
+ * NQA_PREC_F32S (taps 1..2 half, 3..5 float): 2.6 times less of that residual error for ~10 % of the speed.
+ * NQA_PREC_F32M4: stages 1..4 (layers 0..9) on two-term weights, stage 5 as NQA_PREC_F32S.  NQA_PREC_F16W: ALL five stages
+ * -- f16 activations x two-term weights throughout, no float stage, every tap half: f16 without its weight rounding. */
+enum { NQA_PREC_F32 = 0, NQA_PREC_BF16 = 1, NQA_PREC_F16 = 2, NQA_PREC_F32S = 3, NQA_PREC_F32M = 4, NQA_PREC_F32M2 = 5,
+       NQA_PREC_F32M4 = 6, NQA_PREC_F16W = 7 };
 /* pyramid stages (1-based count) that run with f16 activations + two-term weights in a mixed mode, 0 otherwise */
-#define NQA_MIXED_STAGES(prec) ((prec) == NQA_PREC_F32M ? 3 : (prec) == NQA_PREC_F32M2 ? 2 : 0)
+#define NQA_MIXED_STAGES(prec) \
+  ((prec) == NQA_PREC_F32M ? 3 : (prec) == NQA_PREC_F32M2 ? 2 : (prec) == NQA_PREC_F32M4 ? 4 : (prec) == NQA_PREC_F16W ? 5 : 0)
 
 enum {
   NQA_OK = 0,

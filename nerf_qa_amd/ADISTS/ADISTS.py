@@ -67,8 +67,8 @@ class ADISTS(torch.nn.Module):
         for k in range(len(self.chns)):
             self.windows.append(self.create_window(self.window_size, self.window_size / 3, self.chns[k]))
         self.precision = precision or os.environ.get("NQA_ADISTS_PRECISION", DEFAULT_PRECISION)
-        if self.precision != "auto" and prec_id(self.precision) in (4, 5):
-            raise ValueError("precision 'f32m' / 'f32m2' is a DISTS mode: A-DISTS needs float precision in every layer "
+        if self.precision != "auto" and prec_id(self.precision) in (4, 5, 6, 7):
+            raise ValueError("the mixed precisions ('f32m', 'f32m2', 'f32m4', 'f16w') are DISTS modes: A-DISTS needs float precision in every layer "
                              "(see the module docstring); use 'auto' (default), 'f32s', 'f32' or the opt-in 'f16'")
         self._packed = {}
         self._ws = ops.Workspace()

@@ -35,13 +35,15 @@ _DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 #   * frames below AUTO_MIN_PIXELS always run in f32s (split-f16 products on float32 activations, <= 1e-6): f16's
 #     |dscore| has a tail above the bar on small frames whose deep-stage statistics run over a handful of pixels
 #     (tools/gpu_stress_small.py: 1 of 800 random frames up to 64x64 at 1.2e-4);
-#   * larger frames run in the FASTEST of four modes that a one-time calibration with these very weights admits:
+#   * larger frames run in the FASTEST of six modes that a one-time calibration with these very weights admits:
 #       f16    one MFMA per product, f16 activations and weights                      (~2.8x the throughput of f32s)
-#       f32m   "mixed": stages 1..3 f16 activations x two-term (hi, lo) weights, 2 MFMAs; stages 4..5 as f32s (~1.4x)
-#       f32m2  the same with only stages 1..2 on two-term weights                     (~1.25x)
+#       f16w   f16 activations x two-term (hi, lo) weights in ALL stages, 2 MFMAs per product       (~1.6x)
+#       f32m4  the same in stages 1..4, stage 5 as f32s                                            (~1.55x)
+#       f32m   ... stages 1..3, stages 4..5 as f32s                                                (~1.4x)
+#       f32m2  ... stages 1..2                                                                     (~1.25x)
 #       f32s   float activations, three-term split products, <= 1e-6                 (always admitted)
 #     The first time it matters, 384 synthetic pairs (256 of 128x128, 128 of 160x192: additive noise at two levels, 5x5
-#     blur, independent content) go through all four on the GPU (~0.1 s).  A mode is admitted when its deviation from
+#     blur, independent content) go through all six on the GPU (~0.15 s).  A mode is admitted when its deviation from
 #     f32s has rms <= AUTO_F16_RMS (2e-5) AND either max <= AUTO_SAFE_MAX (3e-5: more than 3x below the bar, whatever
 #     the tail looks like) or max <= AUTO_F16_BUDGET (6e-5) with max / rms <= AUTO_TAIL (4.2: the deviations look like
 #     noise, not like outliers -- 384 Gaussian samples give 3.2 +- 0.3).
@@ -61,6 +63,8 @@ AUTO_SAFE_MAX = 3e-5    # a max this far below the bar is admitted whatever the 
 AUTO_F16_RMS = 2e-5     # on the rms, always
 AUTO_CAL_SETS = ((256, 128, 128, 20261), (128, 160, 192, 20262))  # (pairs, height, width, seed)
 AUTO_CAL_PAIRS, AUTO_CAL_SIZE = 128, 128
+# the ladder `auto` climbs, fastest first (two-term stages: f16w all five, f32m4 four, f32m three, f32m2 two)
+LADDER = ("f16", "f16w", "f32m4", "f32m", "f32m2", "f32s")
 
 
 def calibration_pairs(dev, n=AUTO_CAL_PAIRS, size=AUTO_CAL_SIZE, seed=20261, width=None):
@@ -198,7 +202,7 @@ class DISTS(torch.nn.Module):
         # fine-tuning has moved alpha/beta, nor on a variant's logit / clamped parametrisation of them)
         ab = np.load(_DATA)
         a, b = torch.from_numpy(ab["alpha"]).to(device), torch.from_numpy(ab["beta"]).to(device)
-        modes = ("f16", "f32m", "f32m2")
+        modes = LADDER[:-1]
         dev_of = {m: [] for m in modes}
         npairs = 0
         for n, h, w, seed in AUTO_CAL_SETS:
@@ -214,7 +218,7 @@ class DISTS(torch.nn.Module):
         report = {"budget": budget, "rms_budget": rms_budget, "tail_budget": tail_budget, "safe_max": safe_max, "pairs": npairs,
                   "sizes": [f"{n}x {h}x{w}" for n, h, w, _ in AUTO_CAL_SETS]}
         choice = "f32s"
-        for prec in ("f32m2", "f32m", "f16"):  # (the later, faster mode wins if it passes too)
+        for prec in reversed(LADDER[:-1]):  # slowest first: the later, faster mode wins if it passes too
             d = torch.cat(dev_of[prec])
             ok = bool(torch.isfinite(d).all())
             mx = float(d.abs().max()) if ok else float("inf")

@@ -13,12 +13,12 @@ import torch  # noqa: F401  (loads the HIP runtime the library binds to; must co
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NQA_LIB") or os.path.join(_HERE, "libnqa_hip.so")  # NQA_LIB: development builds only
 
-PREC_F32, PREC_BF16, PREC_F16, PREC_F32S, PREC_F32M, PREC_F32M2 = 0, 1, 2, 3, 4, 5
+PREC_F32, PREC_BF16, PREC_F16, PREC_F32S, PREC_F32M, PREC_F32M2, PREC_F32M4, PREC_F16W = 0, 1, 2, 3, 4, 5, 6, 7
 PREC_NAMES = {"f32": PREC_F32, "fp32": PREC_F32, "bf16": PREC_BF16, "f16": PREC_F16, "fp16": PREC_F16,
-              "f32s": PREC_F32S, "f32m": PREC_F32M, "f32m2": PREC_F32M2}
+              "f32s": PREC_F32S, "f32m": PREC_F32M, "f32m2": PREC_F32M2, "f32m4": PREC_F32M4, "f16w": PREC_F16W}
 PREC_DTYPE = {PREC_F32: torch.float32, PREC_BF16: torch.bfloat16, PREC_F16: torch.float16, PREC_F32S: torch.float32}
 # NQA_MIXED_STAGES: the mixed modes run their first pyramid stages as f16 kernels on two-term weights, the rest as f32s
-MIXED_STAGES = {PREC_F32M: 3, PREC_F32M2: 2}
+MIXED_STAGES = {PREC_F32M: 3, PREC_F32M2: 2, PREC_F32M4: 4, PREC_F16W: 5}
 
 
 def stage_prec(prec: int, stage: int) -> int:

@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 # an opt-in mode measured at up to 3.1e-4 on small frames with the stand-in weights (its
 # 8-bit mantissa rounds every stored activation at 2^-9); it is held to 5e-4 and
 # documented in DESIGN.md as NOT meeting the bar.
-SCORE_TOL = {"f32": 1e-4, "f32s": 1e-4, "f32m": 1e-4, "f32m2": 1e-4, "f16": 1e-4, "bf16": 5e-4}
+SCORE_TOL = {"f32": 1e-4, "f32s": 1e-4, "f32m": 1e-4, "f32m2": 1e-4, "f32m4": 1e-4, "f16w": 1e-4, "f16": 1e-4, "bf16": 5e-4}
 
 
 @pytest.fixture(scope="module")
@@ -29,7 +29,7 @@ def dev():
 @pytest.fixture(scope="module")
 def packed(np_convs, dev):
     from nerf_qa_amd import ops
-    return {p: ops.pack_vgg_weights(np_convs, p).to(dev) for p in ("f32", "f32s", "f32m", "f32m2", "f16", "bf16")}
+    return {p: ops.pack_vgg_weights(np_convs, p).to(dev) for p in ("f32", "f32s", "f32m", "f32m2", "f32m4", "f16w", "f16", "bf16")}
 
 
 def _load_case(path):
@@ -45,7 +45,7 @@ DISTS_GOLD = sorted(glob.glob(os.path.join(GOLDEN, "dists_*.npz")))
 # s_tol gates the per-channel maximum for f32 and the channel-mean for the 16-bit paths: at
 # stage 5 of a 20x20 input the statistics run over 4 pixels, where a single rounded
 # activation moves one channel's S2 by O(0.1) while the score stays within 1e-5.
-@pytest.mark.parametrize("prec,s_tol", [("f32", 5e-4), ("f32s", 5e-4), ("f32m", 5e-3), ("f32m2", 5e-3), ("f16", 5e-3), ("bf16", 4e-2)])
+@pytest.mark.parametrize("prec,s_tol", [("f32", 5e-4), ("f32s", 5e-4), ("f32m", 5e-3), ("f32m2", 5e-3), ("f32m4", 5e-3), ("f16w", 5e-3), ("f16", 5e-3), ("bf16", 4e-2)])
 @pytest.mark.parametrize("path", DISTS_GOLD, ids=[os.path.basename(p)[:-4] for p in DISTS_GOLD])
 def test_dists_vs_golden(path, prec, s_tol, packed, alpha_beta, dev):
     from nerf_qa_amd import ops
@@ -62,7 +62,7 @@ def test_dists_vs_golden(path, prec, s_tol, packed, alpha_beta, dev):
     assert e1 <= s_tol and e2 <= s_tol
 
 
-@pytest.mark.parametrize("prec,rtol", [("f32", 3e-5), ("f32s", 3e-5), ("f32m", 2e-3), ("f32m2", 2e-3), ("f16", 4e-3), ("bf16", 3e-2)])
+@pytest.mark.parametrize("prec,rtol", [("f32", 3e-5), ("f32s", 3e-5), ("f32m", 2e-3), ("f32m2", 2e-3), ("f32m4", 2e-3), ("f16w", 2e-3), ("f16", 4e-3), ("bf16", 3e-2)])
 def test_pyramid_taps(prec, rtol, packed, oracle_convs, dev):
     """forward_once: every tapped map against the oracle, odd size so every stage is ragged."""
     from nerf_qa_amd import ops, synth
@@ -83,7 +83,7 @@ def test_identical_inputs_score_zero(packed, alpha_beta, dev):
     from nerf_qa_amd import ops, synth
     x, _ = synth.frame_batch([9], 64, 80)
     x = torch.from_numpy(x).to(dev)
-    for prec in ("f32", "f32s", "f32m", "f32m2", "f16", "bf16"):
+    for prec in ("f32", "f32s", "f32m", "f32m2", "f32m4", "f16w", "f16", "bf16"):
         s1, s2 = ops.dists_forward(x, x.clone(), packed[prec], prec)
         alpha, beta = alpha_beta
         score = ops.dists_score(s1, s2, alpha.to(dev), beta.to(dev))

@@ -29,14 +29,14 @@ def models(dev):
              "a16": ADISTS(precision="f16").to(dev).eval(), "a32": ADISTS(precision="f32").to(dev).eval(),
              "a32s": ADISTS(precision="f32s").to(dev).eval(), "f32s": DISTS(precision="f32s").to(dev).eval()}
         # the shipped defaults: DISTS "auto" = f32s below 96x96 pixels and, above, the fastest mode the one-time
-        # calibration of the module's VGG weights admits (the gain-1.0 stand-ins: f32m); A-DISTS auto = f32 / f32s by size
+        # calibration of the module's VGG weights admits (the gain-1.0 stand-ins: f16w); A-DISTS auto = f32 / f32s by size
         d = DISTS().to(dev)
         assert d.precision == "auto" and d.precision_for(64, 64) == "f32s"
         rep = d.calibrate(dev)
         print("auto calibration:", rep)
-        assert rep["choice"] == "f32m" and rep["f32m"]["ok"] and rep["f32m"]["max_abs_diff"] <= 3e-5 and not rep["f16"]["ok"]
-        assert rep["budget"] == 6e-5 and rep["pairs"] == 384
-        assert d.precision_for(256, 256) == "f32m" and d.precision_for(1080, 1920) == "f32m"
+        assert rep["choice"] == "f16w" and rep["f16w"]["ok"] and rep["f16w"]["max_abs_diff"] <= 3e-5 and not rep["f16"]["ok"]
+        assert rep["budget"] == 6e-5 and rep["pairs"] == 384 and rep["f32m"]["ok"] and rep["f32m2"]["ok"]
+        assert d.precision_for(256, 256) == "f16w" and d.precision_for(1080, 1920) == "f16w"
         with pytest.raises(Exception):
             DISTS().precision_for(256, 256)  # on the CPU there is nothing to calibrate on
         a = ADISTS()

@@ -25,6 +25,7 @@ def models():
         warnings.simplefilter("ignore")
         return {"f16": DISTS(precision="f16").to(dev).eval(), "f32s": DISTS(precision="f32s").to(dev).eval(),
                 "f32m": DISTS(precision="f32m").to(dev).eval(), "f32m2": DISTS(precision="f32m2").to(dev).eval(),
+                "f32m4": DISTS(precision="f32m4").to(dev).eval(), "f16w": DISTS(precision="f16w").to(dev).eval(),
                 "bf16": DISTS(precision="bf16").to(dev).eval(), "a32s": ADISTS(precision="f32s").to(dev).eval(),
                 "a_auto": ADISTS().to(dev).eval()}
 
@@ -42,7 +43,7 @@ def test_random_shape(h, w, models, oracle_convs):
     ref = dists_oracle.dists(x, y, oracle_convs, m.alpha.detach().cpu(), m.beta.detach().cpu())
     aref = adists_oracle.adists(x, y, oracle_convs)
     with torch.no_grad():
-        for key, tol in (("f32s", 5e-6), ("f32m2", 1e-4), ("f32m", 1e-4), ("f16", 1e-4), ("bf16", 1e-3)):
+        for key, tol in (("f32s", 5e-6), ("f32m2", 1e-4), ("f32m", 1e-4), ("f32m4", 1e-4), ("f16w", 1e-4), ("f16", 1e-4), ("bf16", 1e-3)):
             got = models[key](x.to(dev), y.to(dev)).cpu()
             assert got.shape == ref.shape and (got - ref).abs().max().item() <= tol, (key, h, w, got, ref)
         got = models["a32s"](x.to(dev), y.to(dev), as_loss=False).cpu()
@@ -75,7 +76,7 @@ class _GuardedWorkspace:
         return bool((self.full[:g] == 0xA5).all() and (self.full[g + self.n:] == 0xA5).all())
 
 
-@pytest.mark.parametrize("prec", ["f16", "f32s", "f32m", "f32m2"])
+@pytest.mark.parametrize("prec", ["f16", "f32s", "f32m", "f32m2", "f32m4", "f16w"])
 @pytest.mark.parametrize("h,w", [(1, 1), (2, 3), (1, 12), (3, 2), (7, 9), (17, 40), (33, 2), (64, 48), (97, 131)],
                          ids=lambda v: str(v))
 def test_no_write_outside_the_workspace(h, w, prec, np_convs):
@@ -86,7 +87,7 @@ def test_no_write_outside_the_workspace(h, w, prec, np_convs):
     xn, yn = synth.frame_batch([5, 6], h, w)
     x, y = torch.from_numpy(xn).to(dev), torch.from_numpy(yn).to(dev)
     calls = [lambda ws: ops.dists_forward(x, y, packed, prec, ws), lambda ws: ops.vgg_pyramid(x, packed, prec, ws)]
-    if prec not in ("f32m", "f32m2"):  # (DISTS modes: A-DISTS refuses them)
+    if prec not in ("f32m", "f32m2", "f32m4", "f16w"):  # (DISTS modes: A-DISTS refuses them)
         calls.append(lambda ws: ops.adists_forward(x, y, packed, prec, ws, with_map=True))
     for call in calls:
         ws = _GuardedWorkspace()

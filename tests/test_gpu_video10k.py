@@ -36,8 +36,8 @@ def test_video_1080p_three_batches_equal_direct_calls(dev):
             direct.append(net(ref, ren))
         direct = torch.cat(direct)
     # a pair's score does not depend on its batch neighbours.  The statistics' block partition follows the batch size,
-    # so with float taps (the default here calibrates to f32m: taps 4..5 are float) the float32 partial sums of a
-    # channel are grouped differently -- 1e-7; with half taps (f16) every partial sum is exact and the scores bit-equal
+    # so with float taps (f32s, the mixed modes' deep stages) the float32 partial sums of a channel are grouped
+    # differently -- 1e-7; with half taps only (f16, f16w) every partial sum is exact and the scores are bit-equal
     assert (scores - direct).abs().max().item() <= 3e-7, (scores - direct).abs().max().item()
     net16 = DISTS(vgg16_path="synth:1234", precision="f16").to(dev).eval()
     with torch.no_grad():

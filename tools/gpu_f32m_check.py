@@ -17,7 +17,7 @@ oc = dists_oracle.convs_from_numpy(convs)
 x, _ = synth.frame_batch([5, 6], 97, 131)
 x = torch.from_numpy(x)
 ref = dists_oracle.vgg_pyramid(x, oc)[1:]
-for prec in ("f16", "f32m", "f32m2", "f32s"):
+for prec in ("f16", "f16w", "f32m4", "f32m", "f32m2", "f32s"):
     packed = ops.pack_vgg_weights(convs, prec).to(dev)
     taps = ops.vgg_pyramid(x.to(dev), packed, prec)
     errs = []
@@ -35,7 +35,7 @@ for (b, h, w) in ((8, 1080, 1920), (32, 256, 256)):
     xx = torch.rand(b, 3, h, w, device=dev, generator=g)
     yy = (xx + 0.1 * torch.randn(xx.shape, device=dev, generator=g)).clamp_(0, 1)
     base = None
-    for prec in ("f32s", "f32m2", "f32m", "f16"):
+    for prec in ("f32s", "f32m2", "f32m", "f32m4", "f16w", "f16"):
         m = DISTS(precision=prec, vgg16_path="synth:1234").to(dev).eval()
         with torch.no_grad():
             for _ in range(3):

@@ -20,7 +20,7 @@ torch.set_num_threads(16)
 for gain in GAINS:
     spec = f"synth:1234:{gain}"
     convs = dists_oracle.convs_from_numpy(synth.vgg16_weights(1234, gain))
-    models = {p: DISTS(precision=p, vgg16_path=spec).to(dev).eval() for p in ("f16", "f32m", "f32m2", "f32s")}
+    models = {p: DISTS(precision=p, vgg16_path=spec).to(dev).eval() for p in ("f16", "f16w", "f32m4", "f32m", "f32m2", "f32s")}
     auto = DISTS(vgg16_path=spec).to(dev).eval()
     choice = auto.calibrate(dev)["choice"]
     a, b = auto.alpha.detach().cpu(), auto.beta.detach().cpu()
@@ -36,7 +36,7 @@ for gain in GAINS:
             ref = dists_oracle.dists(x, y, convs, a, b)
             for p, m in models.items():
                 errs[p] += (m(x.to(dev), y.to(dev)).cpu() - ref).abs().tolist()
-    line = f"gain {gain} (auto -> {choice}), {sum(len(v) for v in errs.values()) // 4} pairs of {LO}..{HI} px:"
+    line = f"gain {gain} (auto -> {choice}), {sum(len(v) for v in errs.values()) // 6} pairs of {LO}..{HI} px:"
     for p, v in errs.items():
         v = np.array(v)
         line += f"  {p}: max {v.max():.2e} p99 {np.quantile(v, 0.99):.2e} rms {np.sqrt((v * v).mean()):.2e}"
