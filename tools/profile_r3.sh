@@ -14,7 +14,8 @@ run_trace() {  # tag, bench args...
   echo "trace $tag done" >> $R/gpurun_out/prof_r3.progress
 }
 if [ "$WHAT" != "pmc" ]; then
-  run_trace 1080p_auto --steps 6 --warmup 2              # the shipped default (calibrates; f32m on the stand-in weights)
+  run_trace 1080p_auto --steps 6 --warmup 2              # the shipped default (calibrates; f16w on the stand-in weights)
+  run_trace 1080p_f16w --steps 6 --warmup 2 --precision f16w
   run_trace 1080p_f16 --steps 10 --warmup 3 --precision f16
   run_trace 1080p_f32m --steps 6 --warmup 2 --precision f32m
   run_trace 1080p_f32s --steps 5 --warmup 2 --precision f32s
@@ -24,14 +25,14 @@ if [ "$WHAT" != "pmc" ]; then
 fi
 if [ "$WHAT" != "trace" ]; then
   for C in FETCH_SIZE WRITE_SIZE; do
-    for W in 1080p:f16 1080p:f32m 1080p:f32s 256:f16 adists1080p:f32s; do
+    for W in 1080p:f16w 1080p:f16 1080p:f32m 1080p:f32s 256:f16w 256:f16 adists1080p:f32s; do
       wl=${W%%:*}; pr=${W##*:}
       rm -rf $OUT/pmc_${C}_${wl}_${pr}
       rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_${C}_${wl}_${pr} -- python3 $R/bench.py --workload $wl --precision $pr --steps 2 --warmup 1 --only --no-cpu-baseline > /dev/null 2> $OUT/pmc_${C}_${wl}_${pr}.err
       echo "pmc $C $wl $pr done" >> $R/gpurun_out/prof_r3.progress
     done
   done
-  for W in 1080p:f16 1080p:f32m 256:f16; do
+  for W in 1080p:f16w 1080p:f16 1080p:f32m 256:f16w; do
     wl=${W%%:*}; pr=${W##*:}
     rm -rf $OUT/pmc_mfma_${wl}_${pr}
     rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma_${wl}_${pr} -- python3 $R/bench.py --workload $wl --precision $pr --steps 2 --warmup 1 --only --no-cpu-baseline > /dev/null 2> $OUT/pmc_mfma_${wl}_${pr}.err
