@@ -10,18 +10,18 @@ command itself as a CHILD process (before anything touches the GPU), relays rank
 child's code; under an external launcher (WORLD_SIZE set) it is one of the N ranks.
 
 The line's `value` is the headline workload, BASELINE.json configs[2]: B=8 pairs of 1920x1080 per GPU per
-step through DISTS.forward in its shipped precision mode -- "auto": the fastest of f16 / f32m / f32m2 / f32s that the
-module's one-time calibration of its VGG weights admits (384 synthetic pairs through all four; a mode is admitted when
-its deviation from f32s stays well inside the 1e-4 bar AND looks like noise rather than outliers, DISTS_pt.py header).
-For the stand-in weights used here that is f32m (two MFMAs per product in conv layers 1..6, three behind) -- f16 is
-refused (6.5e-5 on the calibration set) -- and the line says so in `dtype`, `config.precision` and
-`config.auto_calibration`.  Frames are resident in HBM.  Frames
+step through DISTS.forward in its shipped precision mode -- "auto": the fastest of f16 / f16w / f32m4 / f32m / f32m2 /
+f32s that the module's one-time calibration of its VGG weights admits (384 synthetic pairs through every rung; a mode is
+admitted when its deviation from f32s stays well inside the 1e-4 bar AND looks like noise rather than outliers,
+DISTS_pt.py header).  For the stand-in weights used here that is f16w (f16 activations x two-term weights: two MFMAs per
+product) -- plain f16 is refused (6.5e-5 on the calibration set) -- and the line says so in `dtype`, `config.precision`
+and `config.auto_calibration`.  Frames are resident in HBM.  Frames
 shard across ranks with no data-path collective; the only exchange is ONE all-gather of the per-frame scores
 after the last step (inside the timed region) -- weak scaling, K steps of 8 pairs on every GPU.
 
 At N=1 the same JSON line also carries, under "workloads", the rest of the metric ("1080p & 256^2", DISTS
 and A-DISTS) measured the same way in the same process: 1080p in f16 (the opt-in fast mode: one MFMA per product; NOT
-what any of the pinned weight sets calibrates to), in f32m2 and in f32s (float32 activations, split-f16 products: the
+what any of the pinned weight sets calibrates to), in f32m / f32m2 and in f32s (float32 activations, split-f16 products: the
 reference's own precision class, what `auto` runs when nothing faster is admitted), 256x256 B=32 (configs[1]) in f16 /
 f32m / f32s, and A-DISTS at 1080p B=8 (configs[4], f32s).  Every entry has its own
 `roofline` (the MFMA conv stack: algorithmic FLOPs of layers 1..12 / the HIP-event time of those launches, measured
