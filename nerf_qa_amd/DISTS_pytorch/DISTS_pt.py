@@ -182,10 +182,10 @@ class DISTS(torch.nn.Module):
 
     @torch.no_grad()
     def calibrate(self, device, force: bool = False) -> dict:
-        """Measure f16 and f32m against f32s with this module's VGG weights on `device` (once per weight set and
-        device) and decide what `auto` runs frames of >= AUTO_MIN_PIXELS in: the fastest of f16 / f32m / f32m2 / f32s
-        whose deviation from f32s stays inside the budgets.  Returns the report {"choice", "f16": {max_abs_diff,
-        rms_diff, ok}, "f32m": {...}, "f32m2": {...}, "budget", "rms_budget", "pairs", "size"}."""
+        """Measure every faster rung of LADDER against f32s with this module's VGG weights on `device` (once per weight
+        set and device) and decide what `auto` runs frames of >= AUTO_MIN_PIXELS in: the fastest mode whose deviation
+        from f32s stays inside the budgets (module header).  Returns the report {"choice", "<mode>": {max_abs_diff,
+        rms_diff, tail, ok} for every rung, "budget", "rms_budget", "tail_budget", "safe_max", "pairs", "sizes"}."""
         device = torch.device(device)
         if device.type != "cuda":
             raise NqaError("precision='auto' calibrates on the GPU: move the module to cuda first "

@@ -8,7 +8,7 @@ fetched here, so every precision margin in README / DESIGN was measured on deter
 who holds the file runs this once; it has no download path.  It prints
   1. the activation magnitudes of the five tapped maps with the real weights next to the stand-ins of gain 1.0 / 1.3 /
      1.6 (so the margins quoted per gain can be read for the real network);
-  2. what DISTS' `auto` precision calibrates to with these weights (the fastest of f16 / f32m / f32m2 whose deviation from
+  2. what DISTS' `auto` precision calibrates to with these weights (the fastest of f16 / f16w / f32m4 / f32m / f32m2 whose deviation from
      f32s over 384 synthetic pairs is small and noise-like: rms <= 2e-5 and (max <= 3e-5, or max <= 6e-5 with max / rms
      <= 4.2); f32s otherwise);
   3. max |score - CPU oracle| of every HIP precision mode on samples of BASELINE.json configs[1] (256x256 pairs),
@@ -90,7 +90,7 @@ def main():
         t_cpu = time.time() - t0
         line = f"   {tag:<34} oracle {ref.min():.4f}..{ref.max():.4f} ({t_cpu:.0f} s CPU)"
         out = {}
-        modes = ("default", "f32s", "f32m2", "f32m", "f16", "f32") if not adists else ("default", "f32s", "f32", "f16")
+        modes = ("default", "f32s", "f32m2", "f32m", "f32m4", "f16w", "f16", "f32") if not adists else ("default", "f32s", "f32", "f16")
         for mode in modes:
             cls = ADISTS if adists else DISTS
             m = cls(precision=None if mode == "default" else mode, vgg16_path=args.weights).to(dev).eval()
