@@ -67,6 +67,16 @@ AUTO_CAL_PAIRS, AUTO_CAL_SIZE = 128, 128
 LADDER = ("f16", "f16w", "f32m4", "f32m", "f32m2", "f32s")
 
 
+def admitted(mx: float, rms: float, budget: float = AUTO_F16_BUDGET, rms_budget: float = AUTO_F16_RMS,
+             tail_budget: float = AUTO_TAIL, safe_max: float = AUTO_SAFE_MAX) -> bool:
+    """`auto`'s admission rule for one mode, from the max and rms of its deviation from f32s over the calibration
+    pairs: the rms small, and the max either far below the bar or moderately below it with a noise-like tail."""
+    if not (mx == mx and rms == rms) or mx == float("inf"):  # NaN / inf: never
+        return False
+    tail = mx / rms if rms > 0 else 0.0
+    return rms <= rms_budget and (mx <= safe_max or (mx <= budget and tail <= tail_budget))
+
+
 def calibration_pairs(dev, n=AUTO_CAL_PAIRS, size=AUTO_CAL_SIZE, seed=20261, width=None):
     """An (x, y) batch `auto` calibrates on: smooth-plus-noise frames (so that blur changes structure) and the four
     distortion families of SURVEY 8d, generated on the device from a fixed seed (size x width pixels, square by default)."""
@@ -225,7 +235,7 @@ class DISTS(torch.nn.Module):
             rms = float(d.pow(2).mean().sqrt()) if ok else float("inf")
             tail = mx / rms if ok and rms > 0 else 0.0
             report[prec] = {"max_abs_diff": mx, "rms_diff": rms, "tail": tail,
-                            "ok": ok and rms <= rms_budget and (mx <= safe_max or (mx <= budget and tail <= tail_budget))}
+                            "ok": ok and admitted(mx, rms, budget, rms_budget, tail_budget, safe_max)}
             if report[prec]["ok"]:
                 choice = prec
         report["choice"] = choice
