@@ -243,7 +243,7 @@ def make_model(metric, precision, dev, h, w):
     net = DISTS(precision=precision, vgg16_path=VGG).to(dev).eval()
     prec = net.precision_for(h, w)  # "auto" (the default) calibrates f16 against f32s with these weights, once
     if net.precision == "auto":
-        AUTO_REPORT.update({k: (round(v, 9) if isinstance(v, float) else v) for k, v in net.calibrate(dev).items()})
+        AUTO_REPORT.update({k: (round(v, 9) if isinstance(v, float) else v) for k, v in net.calibrate(dev, h, w).items()})
     return net, prec, net.vgg_source
 
 

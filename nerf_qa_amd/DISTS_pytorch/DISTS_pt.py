@@ -61,7 +61,26 @@ AUTO_F16_BUDGET = 6e-5  # on max |score_mode - score_f32s| over the calibration 
 AUTO_TAIL = 4.2         # ... and then only if max / rms looks like noise (384 Gaussian samples: 3.2 +- 0.3), not outliers;
 AUTO_SAFE_MAX = 3e-5    # a max this far below the bar is admitted whatever the shape of the tail
 AUTO_F16_RMS = 2e-5     # on the rms, always
-AUTO_CAL_SETS = ((256, 128, 128, 20261), (128, 160, 192, 20262))  # (pairs, height, width, seed)
+# The calibration is taken PER FRAME-SIZE CLASS, at the small end of the class: the outliers of the faster modes sit in
+# single nearly-dead channels of tap 5, whose statistics run over H/16 x W/16 pixels (64 at 128x128, 8160 at 1080p), so
+# what 128x128 frames refuse, 1080p frames may well allow (tools/gpu_size_study.py, tools/gpu_outlier_study.py).
+# (first pixel count of the class, ((pairs, height, width, seed), ...)); frames below the first class run in f32s.
+AUTO_CLASSES = (
+    (96 * 96, ((256, 128, 128, 20261), (128, 160, 192, 20262))),
+    (224 * 224, ((320, 256, 256, 20263), (64, 320, 448, 20264))),
+    (640 * 640, ((192, 640, 640, 20265), (64, 600, 1000, 20266))),
+    (900 * 1000, ((224, 720, 1280, 20267), (32, 1080, 1920, 20268))),
+)
+AUTO_CAL_SETS = AUTO_CLASSES[0][1]
+
+
+def size_class(h: int, w: int) -> int:
+    """Index of the calibration class of an h x w frame (-1: below AUTO_MIN_PIXELS, always f32s)."""
+    k = -1
+    for i, (first, _) in enumerate(AUTO_CLASSES):
+        if h * w >= first:
+            k = i
+    return k
 AUTO_CAL_PAIRS, AUTO_CAL_SIZE = 128, 128
 # the ladder `auto` climbs, fastest first (two-term stages: f16w all five, f32m4 four, f32m three, f32m2 two)
 LADDER = ("f16", "f16w", "f32m4", "f32m", "f32m2", "f32s")
@@ -171,7 +190,7 @@ class DISTS(torch.nn.Module):
             prec_id(self.precision)  # validate early
         self._packed = {}
         self._ws = ops.Workspace()
-        self._auto = None  # (weights key, "f16" | "f32s", report) once calibrated
+        self._auto = None  # (weights key, {size class: report}) once calibrated
 
     # ---- plumbing -----------------------------------------------------------------
     def _conv_modules(self):
@@ -188,21 +207,26 @@ class DISTS(torch.nn.Module):
             return self.precision
         if h * w < AUTO_MIN_PIXELS:
             return "f32s"
-        return self.calibrate(device if device is not None else self.alpha.device)["choice"]
+        return self.calibrate(device if device is not None else self.alpha.device, h, w)["choice"]
 
     @torch.no_grad()
-    def calibrate(self, device, force: bool = False) -> dict:
-        """Measure every faster rung of LADDER against f32s with this module's VGG weights on `device` (once per weight
-        set and device) and decide what `auto` runs frames of >= AUTO_MIN_PIXELS in: the fastest mode whose deviation
-        from f32s stays inside the budgets (module header).  Returns the report {"choice", "<mode>": {max_abs_diff,
-        rms_diff, tail, ok} for every rung, "budget", "rms_budget", "tail_budget", "safe_max", "pairs", "sizes"}."""
+    def calibrate(self, device, h: int = 128, w: int = 128, force: bool = False) -> dict:
+        """Measure every faster rung of LADDER against f32s with this module's VGG weights on `device`, for the
+        frame-size class of h x w (once per weight set, device and class), and decide what `auto` runs frames of that
+        class in: the fastest mode whose deviation from f32s stays inside the budgets (module header).  Returns the
+        report {"choice", "<mode>": {max_abs_diff, rms_diff, tail, ok} for every rung, "budget", "rms_budget",
+        "tail_budget", "safe_max", "pairs", "sizes", "size_class"}."""
         device = torch.device(device)
         if device.type != "cuda":
             raise NqaError("precision='auto' calibrates on the GPU: move the module to cuda first "
                            "(or name a precision: 'f32s' holds 1e-4 unconditionally, 'f16' is the fast mode)")
+        cls = max(size_class(h, w), 0)
         key = self._weights_key(device)
-        if not force and self._auto is not None and self._auto[0] == key:
-            return self._auto[2]
+        if self._auto is None or self._auto[0] != key:
+            self._auto = (key, {})
+        if not force and cls in self._auto[1]:
+            return self._auto[1][cls]
+        cal_sets = AUTO_CLASSES[cls][1]
         budget = float(os.environ.get("NQA_AUTO_F16_BUDGET", AUTO_F16_BUDGET))
         rms_budget = float(os.environ.get("NQA_AUTO_F16_RMS", AUTO_F16_RMS))
         tail_budget = float(os.environ.get("NQA_AUTO_TAIL", AUTO_TAIL))
@@ -215,20 +239,24 @@ class DISTS(torch.nn.Module):
         modes = LADDER[:-1]
         dev_of = {m: [] for m in modes}
         npairs = 0
-        for n, h, w, seed in AUTO_CAL_SETS:
-            x, y = calibration_pairs(device, n=n, size=h, seed=seed, width=w)
+        for n, ch, cw, seed in cal_sets:
+            bs = max(1, min(n, (64 * 128 * 128) // (ch * cw) * 4))  # batches of a few hundred MB of frames
+            for i0 in range(0, n, bs):
+                x, y = calibration_pairs(device, n=min(bs, n - i0), size=ch, seed=seed + 1000 * (i0 // bs), width=cw)
+                score = {}
+                for prec in modes + ("f32s",):
+                    s1, s2 = ops.dists_forward(x, y, self._packed_weights(device, prec), prec, ws)
+                    score[prec] = ops.dists_score(s1, s2, a, b)
+                for m in modes:
+                    dev_of[m].append((score[m] - score["f32s"]).double())
+                del x, y
             npairs += n
-            score = {}
-            for prec in modes + ("f32s",):
-                s1, s2 = ops.dists_forward(x, y, self._packed_weights(device, prec), prec, ws)
-                score[prec] = ops.dists_score(s1, s2, a, b)
-            for m in modes:
-                dev_of[m].append((score[m] - score["f32s"]).double())
-            del x, y
         report = {"budget": budget, "rms_budget": rms_budget, "tail_budget": tail_budget, "safe_max": safe_max, "pairs": npairs,
-                  "sizes": [f"{n}x {h}x{w}" for n, h, w, _ in AUTO_CAL_SETS]}
-        choice = "f32s"
-        for prec in reversed(LADDER[:-1]):  # slowest first: the later, faster mode wins if it passes too
+                  "size_class": cls, "class_from_pixels": AUTO_CLASSES[cls][0],
+                  "sizes": [f"{n}x {ch}x{cw}" for n, ch, cw, _ in cal_sets]}
+        choice, chain = "f32s", True
+        for prec in reversed(LADDER[:-1]):  # most accurate first; a rung is admitted only if every more accurate one is:
+            # a pass above a failure means the sample happened to miss the faster rung's outliers (heavy-tailed weights)
             d = torch.cat(dev_of[prec])
             ok = bool(torch.isfinite(d).all())
             mx = float(d.abs().max()) if ok else float("inf")
@@ -236,17 +264,22 @@ class DISTS(torch.nn.Module):
             tail = mx / rms if ok and rms > 0 else 0.0
             report[prec] = {"max_abs_diff": mx, "rms_diff": rms, "tail": tail,
                             "ok": ok and admitted(mx, rms, budget, rms_budget, tail_budget, safe_max)}
-            if report[prec]["ok"]:
+            chain = chain and report[prec]["ok"]
+            report[prec]["admitted"] = chain
+            if chain:
                 choice = prec
         report["choice"] = choice
         # (kept for readers of earlier reports: the f16 comparison at top level)
         report["max_abs_diff"], report["rms_diff"] = report["f16"]["max_abs_diff"], report["f16"]["rms_diff"]
         del ws
-        self._auto = (key, report["choice"], report)
+        self._auto[1][cls] = report
         return report
 
     def _packed_weights(self, dev, prec=None):
-        prec = prec or self.precision_for(1 << 12, 1 << 12, dev)
+        if prec is None:
+            if self.precision == "auto":
+                raise NqaError("auto precision depends on the frame size: name the mode (precision_for(h, w, device))")
+            prec = self.precision
         key = self._weights_key(dev)
         convs = self._conv_modules()
         hit = self._packed.get(prec)

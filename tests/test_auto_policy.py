@@ -1,9 +1,10 @@
 """DISTS `auto`'s admission rule (nerf_qa_amd/DISTS_pytorch/DISTS_pt.py::admitted) on the calibration figures the three
-pinned stand-in weight sets were MEASURED at on MI355X (max, rms of |mode - f32s| over the 384 calibration pairs;
-profiles/r03_*) -- the policy, pinned on CPU: which rung each weight set ends on and why."""
+pinned stand-in weight sets were MEASURED at on MI355X (max, rms of |mode - f32s| over the calibration pairs of a
+frame-size class; profiles/r03_cal_classes.txt) -- the policy, pinned on CPU: which rung each weight set
+ends on in each class, and why."""
 import math
 
-MEASURED = {  # gain: {mode: (max, rms)}
+MEASURED = {  # class 0 (96x96 .. 224x224 pixels), gain: {mode: (max, rms)}
     1.0: {"f16": (6.472e-05, 1.341e-05), "f16w": (2.295e-05, 6.19e-06), "f32m4": (1.436e-05, 4.13e-06),
           "f32m": (8.37e-06, 2.47e-06), "f32m2": (4.26e-06, 1.2e-06)},
     1.3: {"f16": (4.0799e-04, 5.074e-05), "f16w": (2.0755e-04, 2.906e-05), "f32m4": (8.488e-05, 1.639e-05),
@@ -13,13 +14,53 @@ MEASURED = {  # gain: {mode: (max, rms)}
 }
 
 
-def _choice(gain):
+MEASURED_BY_CLASS = {  # (class, gain): {mode: (max, rms)} for the larger classes, same run
+    (1, 1.0): {"f16": (3.53e-05, 1.16e-05), "f16w": (1.77e-05, 3.91e-06), "f32m4": (1.11e-05, 2.42e-06),
+               "f32m": (7.17e-06, 1.41e-06), "f32m2": (2.41e-06, 7.80e-07)},
+    (3, 1.0): {"f16": (3.77e-05, 1.47e-05), "f16w": (4.43e-06, 1.54e-06), "f32m4": (3.46e-06, 9.20e-07),
+               "f32m": (1.68e-06, 5.70e-07), "f32m2": (1.14e-06, 3.80e-07)},
+    (1, 1.3): {"f16": (3.79e-04, 3.73e-05), "f16w": (1.38e-04, 1.93e-05), "f32m4": (1.54e-04, 1.30e-05),
+               "f32m": (2.66e-05, 4.87e-06), "f32m2": (1.60e-05, 2.70e-06)},
+    (3, 1.3): {"f16": (8.29e-05, 1.12e-05), "f16w": (3.60e-05, 6.59e-06), "f32m4": (2.58e-05, 3.58e-06),
+               "f32m": (9.64e-06, 1.85e-06), "f32m2": (4.98e-06, 8.90e-07)},
+    (3, 1.6): {"f16": (2.51e-04, 3.03e-05), "f16w": (8.90e-05, 1.32e-05), "f32m4": (7.74e-05, 8.89e-06),
+               "f32m": (5.72e-05, 4.96e-06), "f32m2": (4.49e-05, 3.32e-06)},
+    # an under-sampled class (96 pairs of 640x640 / 600x1000 at gain 1.3, an earlier cut): plain f16 happened to miss
+    # its outliers while f16w and f32m4 caught theirs -- the chain rule is what keeps f16 out
+    ("undersampled", 1.3): {"f16": (4.962e-05, 1.305e-05), "f16w": (5.098e-05, 8.07e-06), "f32m4": (6.681e-05, 7.61e-06),
+                            "f32m": (7.88e-06, 1.99e-06), "f32m2": (9.52e-06, 1.41e-06)},
+}
+
+
+def _walk(figures):
+    """The walk DISTS.calibrate() does over its report: most accurate rung first, stop at the first refusal."""
     from nerf_qa_amd.DISTS_pytorch.DISTS_pt import LADDER, admitted
     assert LADDER == ("f16", "f16w", "f32m4", "f32m", "f32m2", "f32s")  # fastest first, f32s always admitted
-    for mode in LADDER[:-1]:
-        if admitted(*MEASURED[gain][mode]):
-            return mode
-    return "f32s"
+    choice = "f32s"
+    for mode in reversed(LADDER[:-1]):
+        if not admitted(*figures[mode]):
+            break
+        choice = mode
+    return choice
+
+
+def _choice(gain):
+    return _walk(MEASURED[gain])
+
+
+def test_larger_frames_calibrate_in_their_own_class():
+    from nerf_qa_amd.DISTS_pytorch.DISTS_pt import AUTO_CLASSES, AUTO_MIN_PIXELS, size_class
+    assert AUTO_CLASSES[0][0] == AUTO_MIN_PIXELS and [c[0] for c in AUTO_CLASSES] == sorted(c[0] for c in AUTO_CLASSES)
+    assert size_class(64, 64) == -1 and size_class(96, 96) == 0 and size_class(223, 224) == 0
+    assert size_class(224, 224) == 1 and size_class(256, 256) == 1 and size_class(480, 640) == 1
+    assert size_class(640, 640) == 2 and size_class(720, 1280) == 3 and size_class(1080, 1920) == 3
+    for first, sets in AUTO_CLASSES:  # every class is calibrated at frames of its own (small end of the) size range
+        assert all(h * w >= first for _, h, w, _ in sets) and sum(n for n, *_ in sets) >= 256
+        assert len({seed for *_, seed in sets}) == len(sets)
+    assert _walk(MEASURED_BY_CLASS[(1, 1.0)]) == "f16" and _walk(MEASURED_BY_CLASS[(3, 1.0)]) == "f16"  # noise-shaped 3.5e-5
+    assert _walk(MEASURED_BY_CLASS[(1, 1.3)]) == "f32m" and _walk(MEASURED_BY_CLASS[(3, 1.3)]) == "f32m4"
+    assert _walk(MEASURED_BY_CLASS[(3, 1.6)]) == "f32s"  # f32m2: 4.5e-5 with a tail of 13.5
+    assert _walk(MEASURED_BY_CLASS[("undersampled", 1.3)]) == "f32m"  # not f16, although f16's own figures pass
 
 
 def test_the_three_pinned_weight_sets_end_on_their_rungs():

@@ -67,24 +67,26 @@ def test_dists_b32_256_vs_reference(gain, dev):
     x, y = _pairs(g, dev)
     assert x.shape[0] == 32
     # THE GATE: the shipped default ("auto") within 1e-4 of the reference on every pinned weight set.  auto calibrates
-    # every rung of its ladder against f32s once with the weights at hand (DISTS_pt.py header, 384 pairs): gain 1.0 runs
-    # in f16w (f16 activations x two-term weights; plain f16 measures 6.5e-5 with an outlier tail: refused), gain 1.3 in
-    # f32m2, gain 1.6 in f32s.
+    # every rung of its ladder against f32s once per frame-size class with the weights at hand (DISTS_pt.py header;
+    # 256x256 frames: 384 pairs of 256x256 / 320x448): gain 1.0 runs in plain f16 (3.5e-5 with a noise-shaped tail),
+    # gain 1.3 in f32m (f32m4 and faster show outliers: refused), gain 1.6 in f32s.
     m = DISTS(vgg16_path=_spec(gain)).to(dev).eval()
     assert m.precision == "auto"
-    rep = m.calibrate(dev)
+    rep = m.calibrate(dev, 256, 256)
+    assert rep["size_class"] == 1 and rep["pairs"] == 384
     with torch.no_grad():
         got = m(x, y).cpu().numpy()
     err = np.abs(got - g["score"]).max()
     print(f"\nDISTS B=32 256x256 gain {gain} DEFAULT (auto -> {rep['choice']}; calibration |f16-f32s| max "
           f"{rep['max_abs_diff']:.2e} rms {rep['rms_diff']:.2e}): max|dscore|={err:.2e}")
     assert err <= 1e-4, ("auto", rep, gain, err)
-    assert rep["choice"] == {1.0: "f16w", 1.3: "f32m2", 1.6: "f32s"}[gain], rep  # (what the pinned sets are known to measure)
+    assert rep["choice"] == {1.0: "f16", 1.3: "f32m", 1.6: "f32s"}[gain], rep  # (what the pinned sets are known to measure)
+    assert m.precision_for(128, 128, dev) == {1.0: "f16w", 1.3: "f32m2", 1.6: "f32s"}[gain]  # smaller frames: a stricter class
     del m
     # per-channel S1 / S2 are quotients with c = 1e-6: on nearly dead channels (variance ~1e-6) a 1e-9 difference in
     # a moment moves S2 by 1e-3, so they get a loose bound; the score (their alpha/beta-weighted sum) is the bar.
-    # Explicitly named modes: f32s / f32 to 5e-6.  Forced f16 (the opt-in fast mode, which auto admits for NONE of the
-    # three pinned sets) is held to 1e-4 on this batch at gain 1.0; at gains 1.3 / 1.6 it is OUT OF SPEC by construction (heavy-tailed error: this batch
+    # Explicitly named modes: f32s / f32 to 5e-6.  Forced f16 (which auto admits at gain 1.0 only, and there only from
+    # 224x224 pixels up) is held to 1e-4 on this batch at gain 1.0; at gains 1.3 / 1.6 it is OUT OF SPEC by construction (heavy-tailed error: this batch
     # lands at 6e-5 / 1e-4, other seeds at 1.3e-4 / 2e-4, tools/gpu_auto_calibration.py) -- that is why auto does not
     # choose it there; the value is printed, not gated (only a sanity bound).
     for prec, tol, stol in (("f16", 1e-4 if gain == 1.0 else None, None), ("f16w", 1e-4 if gain == 1.0 else None, None), ("f32m4", 1e-4 if gain == 1.0 else None, None), ("f32m", 4e-5, None),
@@ -116,7 +118,9 @@ def test_dists_1080p_b8_vs_reference(gain, dev):
     for prec, tol in ((None, 1e-4), ("f16", 1e-4), ("f16w", 1e-4), ("f32m", 4e-5), ("f32s", 2e-5)):  # None = the shipped default (auto)
         m = DISTS(precision=prec, vgg16_path=_spec(gain)).to(dev).eval()
         if prec is None:
-            prec = "auto->" + m.precision_for(1080, 1920, dev)
+            chosen = m.precision_for(1080, 1920, dev)  # class 3: 224 pairs of 720p + 32 of 1080p through every rung
+            assert chosen == {1.0: "f16", 1.6: "f32s"}[gain], m.calibrate(dev, 1080, 1920)
+            prec = "auto->" + chosen
         with torch.no_grad():
             got = m(x, y)
             s1, s2 = m._similarities(x, y)

@@ -28,7 +28,7 @@ for prec in ("f16", "f16w", "f32m4", "f32m", "f32m2", "f32s"):
 
 for gain in (1.0, 1.3, 1.6):
     m = DISTS(vgg16_path=f"synth:1234:{gain}").to(dev).eval()
-    print("gain", gain, m.calibrate(dev), flush=True)
+    print("gain", gain, m.calibrate(dev, 256, 256), flush=True)
 
 for (b, h, w) in ((8, 1080, 1920), (32, 256, 256)):
     g = torch.Generator(device=dev).manual_seed(1)

@@ -1,0 +1,78 @@
+"""The shipped default (`auto`) against f32s on random frame sizes from 96x96 to 1080p, per stand-in weight gain and per
+calibration size class (GPU box): how far the modes the calibration admits really stray on frames it has not seen.
+f32s itself sits within 1e-6 of the CPU oracle (tests/test_gpu_fullsize_golden.py), so the deviation from f32s IS the
+deviation from the reference to that accuracy.  Content differs from the calibration's generator on purpose: random
+noise levels, blur widths, brightness / contrast changes, block artefacts, independent frames.
+usage: python tools/gpu_stress_auto.py [pairs per gain] [gains...]"""
+import math
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, __file__.rsplit("/", 2)[0])
+from nerf_qa_amd.DISTS_pytorch import DISTS  # noqa: E402
+from nerf_qa_amd.DISTS_pytorch.DISTS_pt import AUTO_CLASSES, size_class  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 600
+GAINS = [float(g) for g in sys.argv[2:]] or [1.0, 1.3, 1.6]
+dev = torch.device("cuda:0")
+
+
+def frames(g, rng, h, w):
+    """One (x, y) pair: a textured frame with a smooth component of random scale, and a randomly chosen distortion."""
+    s = int(rng.choice([4, 8, 16, 32]))
+    low = F.interpolate(torch.rand(1, 3, max(h // s, 2), max(w // s, 2), device=dev, generator=g), size=(h, w),
+                        mode="bilinear", align_corners=False)
+    mix = float(rng.uniform(0.2, 0.9))
+    x = (mix * torch.rand(1, 3, h, w, device=dev, generator=g) + (1 - mix) * low).clamp_(0, 1)
+    k = int(rng.integers(0, 6))
+    if k == 0:
+        y = x + float(rng.uniform(0.005, 0.15)) * torch.randn(1, 3, h, w, device=dev, generator=g)
+    elif k == 1:
+        r = int(rng.choice([1, 2, 3]))
+        y = F.avg_pool2d(x, 2 * r + 1, 1, r, count_include_pad=False)
+    elif k == 2:
+        y = x * float(rng.uniform(0.6, 1.2)) + float(rng.uniform(-0.1, 0.1))
+    elif k == 3:  # block artefacts: 8x8 means blended in
+        hb, wb = h // 8 * 8, w // 8 * 8
+        y = x.clone()
+        blk = F.interpolate(F.avg_pool2d(x[..., :hb, :wb], 8), scale_factor=8, mode="nearest")
+        t = float(rng.uniform(0.2, 0.9))
+        y[..., :hb, :wb] = (1 - t) * x[..., :hb, :wb] + t * blk
+    elif k == 4:
+        y = torch.rand(1, 3, h, w, device=dev, generator=g)
+    else:  # a one-pixel shift plus light noise (what a slightly misregistered render looks like)
+        y = torch.roll(x, (int(rng.integers(-1, 2)), 1), (2, 3)) + 0.01 * torch.randn(1, 3, h, w, device=dev, generator=g)
+    return x, y.clamp_(0, 1)
+
+
+worst_overall = 0.0
+for gain in GAINS:
+    spec = f"synth:1234:{gain}"
+    auto = DISTS(vgg16_path=spec).to(dev).eval()
+    exact = DISTS(precision="f32s", vgg16_path=spec).to(dev).eval()
+    rng = np.random.default_rng(777)
+    g = torch.Generator(device=dev).manual_seed(31337)
+    per = {}
+    lo, hi = math.log(96 * 96), math.log(1080 * 1920)
+    for i in range(N):
+        area = math.exp(rng.uniform(lo, hi))
+        aspect = math.exp(rng.uniform(-0.7, 0.7))
+        h = int(min(max(round(math.sqrt(area / aspect)), 64), 1200))
+        w = int(min(max(round(area / h), 64), 2048))
+        x, y = frames(g, rng, h, w)
+        with torch.no_grad():
+            d = abs(float(auto(x, y)) - float(exact(x, y)))
+        per.setdefault(size_class(h, w), []).append((d, h, w))
+    for c in sorted(per):
+        v = np.array([t[0] for t in per[c]])
+        wd = max(per[c])
+        mode = auto.precision_for(wd[1], wd[2], dev) if c >= 0 else "f32s"
+        frm = AUTO_CLASSES[c][0] if c >= 0 else 0
+        print(f"gain {gain} class {c} (>= {frm} px, auto -> {mode}): {len(v)} pairs  max {v.max():.2e} (at {wd[1]}x{wd[2]})  "
+              f"p99 {np.quantile(v, 0.99):.2e}  rms {np.sqrt((v * v).mean()):.2e}", flush=True)
+        worst_overall = max(worst_overall, v.max())
+print(f"worst |auto - f32s| over everything: {worst_overall:.2e}")
+assert worst_overall <= 1e-4

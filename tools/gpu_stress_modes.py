@@ -22,7 +22,7 @@ for gain in GAINS:
     convs = dists_oracle.convs_from_numpy(synth.vgg16_weights(1234, gain))
     models = {p: DISTS(precision=p, vgg16_path=spec).to(dev).eval() for p in ("f16", "f16w", "f32m4", "f32m", "f32m2", "f32s")}
     auto = DISTS(vgg16_path=spec).to(dev).eval()
-    choice = auto.calibrate(dev)["choice"]
+    choice = auto.calibrate(dev, LO, LO)["choice"]  # (the class of the smallest frames drawn)
     a, b = auto.alpha.detach().cpu(), auto.beta.detach().cpu()
     rng = np.random.default_rng(4242)
     errs = {p: [] for p in models}

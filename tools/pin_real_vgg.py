@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 from nerf_qa_amd import ops, synth  # noqa: E402
 from nerf_qa_amd.ADISTS import ADISTS  # noqa: E402
 from nerf_qa_amd.DISTS_pytorch import DISTS  # noqa: E402
-from nerf_qa_amd.DISTS_pytorch.DISTS_pt import calibration_pairs  # noqa: E402
+from nerf_qa_amd.DISTS_pytorch.DISTS_pt import LADDER, calibration_pairs  # noqa: E402
 from nerf_qa_amd.vgg_weights import load_vgg16_convs  # noqa: E402
 from oracle import adists_oracle, dists_oracle  # noqa: E402
 
@@ -74,9 +74,12 @@ def main():
 
     print("\n2. DISTS auto-precision calibration with these weights")
     net = DISTS(vgg16_path=args.weights).to(dev).eval()
-    rep = net.calibrate(dev)
-    print("   ", rep)
-    report["auto_calibration"] = rep
+    report["auto_calibration"] = {}
+    for ch, cw in ((128, 128), (256, 256), (640, 960), (1080, 1920)):  # one frame size in each calibration class
+        rep = net.calibrate(dev, ch, cw)
+        print(f"    class {rep['size_class']} ({' + '.join(rep['sizes'])}) -> {rep['choice']}:",
+              {k: (f"{rep[k]['max_abs_diff']:.2e}", f"{rep[k]['rms_diff']:.2e}", rep[k]["admitted"]) for k in LADDER[:-1]})
+        report["auto_calibration"][f"class{rep['size_class']}"] = rep
 
     alpha, beta = net.alpha.detach().cpu(), net.beta.detach().cpu()
     failures = []
