@@ -42,19 +42,21 @@ _DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 #       f32m   ... stages 1..3, stages 4..5 as f32s                                                (~1.4x)
 #       f32m2  ... stages 1..2                                                                     (~1.25x)
 #       f32s   float activations, three-term split products, <= 1e-6                 (always admitted)
-#     The first time it matters, 384 synthetic pairs (256 of 128x128, 128 of 160x192: additive noise at two levels, 5x5
-#     blur, independent content) go through all six on the GPU (~0.15 s).  A mode is admitted when its deviation from
-#     f32s has rms <= AUTO_F16_RMS (2e-5) AND either max <= AUTO_SAFE_MAX (3e-5: more than 3x below the bar, whatever
-#     the tail looks like) or max <= AUTO_F16_BUDGET (6e-5) with max / rms <= AUTO_TAIL (4.2: the deviations look like
-#     noise, not like outliers -- 384 Gaussian samples give 3.2 +- 0.3).
+#     The first time a frame of a size class arrives (AUTO_CLASSES below), 256..384 synthetic pairs of that class's own
+#     sizes (additive noise at two levels, 5x5 blur, independent content) go through all six on the GPU (0.15 s for the
+#     smallest class, 4.3 s for the 1080p class).  A mode PASSES when its deviation from f32s has rms <= AUTO_F16_RMS
+#     (2e-5) AND either max <= AUTO_SAFE_MAX (3e-5: more than 3x below the bar, whatever the tail looks like) or max <=
+#     AUTO_F16_BUDGET (6e-5) with max / rms <= AUTO_TAIL (4.2: the deviations look like noise, not like outliers -- 384
+#     Gaussian samples give 3.2 +- 0.3); it is ADMITTED when it and every more accurate mode pass.
 # Why a measurement and not a rule: tools/cpu_prec_layers.py shows the 16-bit error is spread evenly over all 13
 # layers and over both operands (weights and activations each ~2.3e-5 rms at stand-in gain 1.6), so no small set of
 # "two-term" layers repairs it -- what decides whether 11-bit operands are enough is how the weights at hand grow
 # the activations with depth, which one cheap comparison on the device answers.  Why the tail test: the deviations of
 # the faster modes are outlier-driven once activations grow (nearly dead channels whose S2 is a quotient of two tiny
 # moments): on 692 random pairs f32m at gain 1.3 has rms 7e-6 but a worst pair of 9.9e-5, f16 at gain 1.0 rms 1.1e-5
-# and 4.8e-5 (profiles/r03_stress_modes_692.txt).  What the three pinned stand-in weight sets calibrate to: gain 1.0 ->
-# f32m (f16: max 6.5e-5, tail 4.8 -- refused), gain 1.3 -> f32m2 (f32m: 6.2e-5, tail 6.3 -- refused), gain 1.6 -> f32s.
+# and 4.8e-5 (profiles/r03_stress_modes_692.txt).  What the three pinned stand-in weight sets calibrate to
+# (profiles/r03_cal_classes.txt): gain 1.0 -> f16w below 224x224 pixels (f16: max 6.5e-5, tail 4.8 -- refused) and plain
+# f16 from there up (3.5e-5, tail 3.0); gain 1.3 -> f32m2 / f32m / f32m / f32m4 by class; gain 1.6 -> f32s everywhere.
 DEFAULT_PRECISION = "auto"
 AUTO_MIN_PIXELS = 96 * 96
 AUTO_F16_BUDGET = 6e-5  # on max |score_mode - score_f32s| over the calibration pairs ...

@@ -14,7 +14,7 @@ run_trace() {  # tag, bench args...
   echo "trace $tag done" >> $R/gpurun_out/prof_r3.progress
 }
 if [ "$WHAT" != "pmc" ]; then
-  run_trace 1080p_auto --steps 6 --warmup 2              # the shipped default (calibrates; f16w on the stand-in weights)
+  run_trace 1080p_auto --steps 6 --warmup 2              # the shipped default (calibrates the 1080p class; f16 on the gain-1.0 stand-in weights)
   run_trace 1080p_f16w --steps 6 --warmup 2 --precision f16w
   run_trace 1080p_f16 --steps 10 --warmup 3 --precision f16
   run_trace 1080p_f32m --steps 6 --warmup 2 --precision f32m
