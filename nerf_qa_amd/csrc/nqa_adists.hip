@@ -1179,7 +1179,10 @@ static int adists_run(const float *x, const float *y, int B, int H, int W, const
 
   // ---- pyramids (x images [0,B), y images [B,2B)) with the global statistics per tap ----
   if ((rc = stats_nchw(x, y, B, 3, H * W, part + p.sd.part_off[0], st))) return rc;
-  const bool fused1 = prec_elem_bytes(prec) == 2;
+  // (f32s: conv1_regw_split_kernel, as in nqa_api.hip's run_stages; frames in f32s are >= 128 x 128 pixels under the
+  // default `auto`, far from the tiny-frame knife edge that made a conv1_1 rounding pattern matter, section 4.4)
+  const bool fused_s = prec == NQA_PREC_F32S && !mixed_stage1_unfused();
+  const bool fused1 = prec_elem_bytes(prec) == 2 || fused_s;
   if (!fused1) {
     if ((rc = conv1_1(x, B, H, W, packed, prec, base + p.bufA, st))) return rc;
     if ((rc = conv1_1(y, B, H, W, packed, prec, base + p.bufA + (size_t)B * H * W * 64 * esz, st))) return rc;
@@ -1192,7 +1195,9 @@ static int adists_run(const float *x, const float *y, int B, int H, int W, const
       const int k = cs.stage;
       void *dst = cs.last ? taps[k] : (cur == bufA ? bufB : bufA);
       if (layer == 1 && fused1) {
-        if ((rc = conv1_fused(x, y, B, 2 * B, H, W, packed, prec, dst, st))) return rc;
+        if ((rc = fused_s ? conv1_fused_split(x, y, B, 2 * B, H, W, packed, dst, st)
+                          : conv1_fused(x, y, B, 2 * B, H, W, packed, prec, dst, st)))
+          return rc;
       } else if ((rc = conv3x3(cur, 2 * B, p.h[k + 1], p.w[k + 1], layer, packed, prec, dst, st))) {
         return rc;
       }

@@ -96,7 +96,9 @@ size_t layer0_mfma_offset(int prec) { return layer_offset(0, prec) + align_up(27
 // (144 VGPRs) once per persistent block.  Appended behind the ordinary layers.
 // (NQA_PREC_F32M: the same fragments for 16 channels per group, once as the f16 `hi` and once as the `lo` part of the
 // scaled weights: [cout/16][part][k-steps][64 lanes][8 halfs])
+// (NQA_PREC_F32S: conv1_2 alone, in the two-term form, for the fused stage-1 kernel conv1_regw_split_kernel)
 size_t regw_bytes(int layer, int prec) {
+  if (prec == NQA_PREC_F32S) return layer == 1 ? (size_t)64 * 64 * 9 * 2 * 2 : 0;
   return (size_t)kConvs[layer].cout * kConvs[layer].cin * 9 * 2 * (is_mixed(prec) ? 2 : 1);
 }
 static const int kRegwFirst = 1, kRegwLast = 4;  // conv1_2, conv2_1 (Cin 64); conv2_2, conv3_1 (Cin 128)
@@ -263,7 +265,10 @@ static int run_stages(const float *x, const float *y, int nx, void *bufA, void *
     }
     return NQA_OK;
   }
-  const bool fused1 = prec_elem_bytes(prec) == 2;
+  // f32s: conv1_regw_split_kernel (three-term products, relu1_1 stays in LDS) unless the first-forms bit asks for the
+  // round-2 pair conv1_1_kernel (VALU, split16 out) + implicit GEMM
+  const bool fused_s = prec == NQA_PREC_F32S && !mixed_stage1_unfused();
+  const bool fused1 = prec_elem_bytes(prec) == 2 || fused_s;
   if (!fused1) {
     if ((rc = conv1_1(x, nx, H, W, packed, prec, bufA, st))) return rc;
     if (n > nx && (rc = conv1_1(y, n - nx, H, W, packed, prec,
@@ -275,7 +280,9 @@ static int run_stages(const float *x, const float *y, int nx, void *bufA, void *
     const int k = cs.stage;
     void *dst = (cs.last && taps) ? taps[k] : (cur == bufA ? bufB : bufA);
     if (layer == 1 && fused1) {
-      if ((rc = conv1_fused(x, y, nx, n, H, W, packed, prec, dst, st))) return rc;
+      if ((rc = fused_s ? conv1_fused_split(x, y, nx, n, H, W, packed, dst, st)
+                        : conv1_fused(x, y, nx, n, H, W, packed, prec, dst, st)))
+        return rc;
     } else if ((rc = conv3x3(cur, n, d.h[k], d.w[k], layer, packed, prec, dst, st))) {
       return rc;
     }
@@ -396,7 +403,8 @@ int nqa_timing_collect(int launches[NQA_K_COUNT], double ms[NQA_K_COUNT]) {
 size_t nqa_packed_weights_bytes(int prec) {
   if (!prec_valid_pyramid(prec)) return 0;
   size_t n = layer_offset(NQA_NUM_CONVS, prec);
-  if (is_mixed(prec) || prec_elem_bytes(prec) == 2) n = layer0_m16_offset(prec) + kW1M16Bytes * (is_mixed(prec) ? 2 : 1);
+  if (is_mixed(prec) || prec_elem_bytes(prec) == 2 || prec == NQA_PREC_F32S)
+    n = layer0_m16_offset(prec) + kW1M16Bytes * (is_mixed(prec) || prec == NQA_PREC_F32S ? 2 : 1);
   return n;
 }
 
@@ -523,8 +531,9 @@ int nqa_pack_vgg_weights(const float *const w_host[NQA_NUM_CONVS], const float *
             }
     memcpy(blob + layer_bias_offset(l, prec), b_host[l], (size_t)cs.cout * 4);
   }
-  if (is_mixed(prec)) {
-    // conv1_1 for conv1_regw_kernel<.., NTERM = 2>: [4 tiles of 16 channels][2 MFMAs][part: hi, lo][64 lanes][8 halfs] of
+  if (is_mixed(prec) || prec == NQA_PREC_F32S) {
+    // conv1_1 for conv1_regw_kernel<.., NTERM = 2> (and, in f32s, conv1_regw_split_kernel): [4 tiles of 16 channels][2
+    // MFMAs][part: hi, lo][64 lanes][8 halfs] of
     // the weights times a power of two; 1 / that scale in the first float of the 32x32-fragment area
     const int k1 = weight_scale_exp(w_host[0], 64 * 27);
     const float s1 = ldexpf(1.f, k1), inv1 = ldexpf(1.f, -k1);
@@ -541,8 +550,8 @@ int nqa_pack_vgg_weights(const float *const w_host[NQA_NUM_CONVS], const float *
               const uint16_t hi = f32_to_f16(v);
               w1[((((size_t)i * 2 + m) * 2 + part) * 64 + lane) * 8 + j] = part == 0 ? hi : f32_to_f16(v - f16_to_f32(hi));
             }
-    // two-term register fragments of layers 1..4 (conv3x3_regw_kernel<.., NTERM = 2> and regw128)
-    for (int l = kRegwFirst; l <= kRegwLast; ++l) {
+    // two-term register fragments of layers 1..4 (conv3x3_regw_kernel<.., NTERM = 2> and regw128; f32s: conv1_2 only)
+    for (int l = kRegwFirst; l <= (prec == NQA_PREC_F32S ? kRegwFirst : kRegwLast); ++l) {
       const ConvSpec &cs = kConvs[l];
       const int nks = cs.cin / 32 * 9;
       const float wscale = ldexpf(1.f, weight_scale_exp(w_host[l], (size_t)cs.cout * cs.cin * 9));  // (as the layer's rows)

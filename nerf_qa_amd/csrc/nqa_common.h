@@ -219,6 +219,9 @@ int conv1_1_blob(const float *x, int n, int H, int W, const void *packed, int bl
 int conv1_fused_blob(const float *x, const float *y, int B, int n, int H, int W, const void *packed, int blob_prec,
                      void *out, hipStream_t st);
 bool mixed_stage1_unfused();  // (A/B switch of nqa_set_conv_variant's first-forms bit)
+// stage 1 of an f32s blob in one kernel (three-term products, float NHWC out), images [x(0..B), y(0..n-B))
+int conv1_fused_split(const float *x, const float *y, int B, int n, int H, int W, const void *packed, void *out,
+                      hipStream_t st);
 int relu_mask_split16(const float *g, const void *act, int act_split, long npix, int C, void *out, hipStream_t st);
 int l2pool_backward(const float *x, const void *y_split16, const float *gy, int n, int H, int W, int C, float *gx,
                     hipStream_t st);

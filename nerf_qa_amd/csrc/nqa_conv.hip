@@ -1253,6 +1253,269 @@ __global__ __launch_bounds__(512) void conv1_regw_kernel(const float *__restrict
 }
 
 // ---------------------------------------------------------------------------------
+// Stage 1 in f32s (conv1_1 + conv1_2, float32-class products), fused on the same principle.
+// ---------------------------------------------------------------------------------
+// What conv1_regw_kernel<PrecF16, 2> is to the two-term modes, with the ACTIVATIONS in two parts as well: a product is
+// a_hi*w_hi + a_hi*w_lo + a_lo*w_hi (three 16x16x32 MFMAs, the dropped a_lo*w_lo is 2^-22 relative), relu1_1 never
+// exists in HBM (the unfused path writes it as 8.5 GB of split16 records per 16 images of 1080p and reads it back),
+// and conv1_1 runs on the matrix cores instead of the VALU (conv1_1_kernel<PrecF32S>).
+//   * 4 x 32 output tiles (an 8-row tile's halo image does not fit twice): the halo is 6 x 34 = 204 pixels; a pixel's
+//     record in the halo image is [32 channels hi | 32 channels lo | 32 B pad] = 160 B per 32-channel chunk, a pitch at
+//     which a ds_read_b128 of 16 consecutive pixels is bank-conflict-free; two images alternate (133 KB);
+//   * the raw patch is 8 x 36 pixels, normalised in float and stored as a hi and a lo plane of [row][col][4 halfs];
+//     conv1_1 = 3 terms x 2 MFMAs (kernel rows 0-1 | row 2) x 4 channel tiles per 16 halo pixels, accumulator started at
+//     bias x scale, descaled, ReLU, zero outside the image, split into (hi, lo) halves and written into the halo image;
+//   * conv1_2: a wave = 16 output channels x 2 tile rows x 32 columns, its (hi, lo) weight fragments in registers (144
+//     VGPRs, the two-term blob format), three accumulators per 16-pixel group (hi*hi | lo_w*hi_a | hi_w*lo_a) summed in
+//     the epilogue; float NHWC out (the tap the statistics and the pool read).
+// Same pipeline as conv1_regw_kernel: one barrier per tile, the two waves of a SIMD take conv1_1 (of the next tile) and
+// conv1_2 (of this one) in opposite order.  LDS: 2 x 66 560 (halo) + 2 x 5 760 (raw) + 16 384 (conv1_1 fragments) + 256.
+__global__ __launch_bounds__(512) void conv1_regw_split_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                               int B, const char *__restrict__ w1m,
+                                                               const float *__restrict__ bias1,
+                                                               const char *__restrict__ wreg,
+                                                               const float *__restrict__ bias2, float *__restrict__ out,
+                                                               int H, int W, int tiles_x, int tiles_y, int total_tiles,
+                                                               const float *__restrict__ w1inv_p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+  constexpr int COUT = 64, TH = 4, TW = 32, HWD = TW + 2, NQ = (TH + 2) * HWD;  // 204 halo pixels
+  constexpr int NGRP = (NQ + 15) / 16, NQP = NGRP * 16;                         // 13 groups of 16, 208 records
+  constexpr int PITCH = 160, LO = 64, CH_BYTES = NQP * PITCH, SLOT = 2 * CH_BYTES;
+  constexpr int RAWP = 40, RAW_ROWS = 9, RAW_PLANE = RAW_ROWS * RAWP * 8, RAW_BYTES = 2 * RAW_PLANE;  // hi plane, lo plane
+  constexpr int RAW_OFF = 2 * SLOT, W1_OFF = RAW_OFF + 2 * RAW_BYTES, B1_OFF = W1_OFF + 2 * 4 * 2 * 64 * 16;
+  constexpr int NG = 4, RW = 2, GPP = 2, NPASS = RW;  // 4 channel groups of 16; a wave: 2 rows x 2 groups of 16 columns
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [halo 0][halo 1][raw 0][raw 1][conv1_1 fragments][bias1]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, c4 = lane >> 4;
+  const int cg = wave % NG, ph = wave / NG;
+  const int HW = H * W;
+  const float w1inv = w1inv_p[0];
+
+  const int nblk = gridDim.x, nx = nblk < 8 ? nblk : 8;
+  const int xcd = blockIdx.x % nx, jb = blockIdx.x / nx;
+  const int blk_per_xcd = (nblk - xcd + nx - 1) / nx;
+  const int t_lo = (int)((long)total_tiles * xcd / nx), t_hi = (int)((long)total_tiles * (xcd + 1) / nx);
+  const int my_tiles = t_lo + jb < t_hi ? (t_hi - t_lo - jb - 1) / blk_per_xcd + 1 : 0;
+  if (my_tiles == 0) return;  // (block-uniform)
+  auto tile_coords = [&](int it, int &n, int &x0, int &y0) {
+    const int t = t_lo + jb + it * blk_per_xcd;
+    n = t / (tiles_x * tiles_y);
+    const int t2 = t - n * (tiles_x * tiles_y), by = t2 / tiles_x;
+    x0 = (t2 - by * tiles_x) * TW;
+    y0 = by * TH;
+  };
+
+  // ---- one-time: conv1_2 (hi, lo) fragments into registers; conv1_1 fragments, bias1 and zeroed raw patches into LDS ----
+  u32x4 wf[2][18];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int ks = 0; ks < 18; ++ks)
+      wf[i][ks] = *reinterpret_cast<const u32x4 *>(wreg + ((((size_t)cg * 2 + i) * 18 + ks) * 64 + lane) * 16);
+  float bia[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) bia[e] = bias2[cg * 16 + 4 * c4 + e];
+  const float winv2 = bias2[COUT];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)  // 8 KB = 512 x 16 B per term
+    reinterpret_cast<u32x4 *>(smem + W1_OFF)[r * 512 + tid] = reinterpret_cast<const u32x4 *>(w1m)[r * 512 + tid];
+  if (tid < 64) reinterpret_cast<float *>(smem + B1_OFF)[tid] = bias1[tid] / w1inv;  // (exact: a power of two)
+  for (int i = tid; i < 2 * RAW_BYTES / 8; i += 512) reinterpret_cast<u32x2 *>(smem + RAW_OFF)[i] = (u32x2){0u, 0u};
+
+  // ---- raw patch: thread t < 288 owns pixel (t / 36, t % 36) of the 8 x 36 patch ----
+  const int r_row = tid / 36, r_col = tid - r_row * 36;
+  const bool r_mine = tid < 8 * 36;
+  const float mean[3] = {0.485f, 0.456f, 0.406f};
+  const float sd[3] = {0.229f, 0.224f, 0.225f};
+  float rv[3];
+  bool r_ok = false;
+  auto raw_fetch = [&](int it) {
+    r_ok = false;
+    rv[0] = rv[1] = rv[2] = 0.f;
+    if (it < my_tiles && r_mine) {
+      int n, x0, y0;
+      tile_coords(it, n, x0, y0);
+      const int gy = y0 - 2 + r_row, gx = x0 - 2 + r_col;
+      r_ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      if (r_ok) {
+        const float *img = (n < B ? x + (size_t)n * 3 * HW : y + (size_t)(n - B) * 3 * HW) + gy * W + gx;
+        rv[0] = img[0];
+        rv[1] = img[HW];
+        rv[2] = img[2 * HW];
+      }
+    }
+  };
+  auto raw_commit = [&](int buf) {
+    if (r_mine) {
+      h4 hi, lo;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float v = r_ok ? (rv[c] - mean[c]) / sd[c] : 0.f;
+        hi[c] = (_Float16)v;
+        lo[c] = (_Float16)(v - (float)hi[c]);
+      }
+      hi[3] = lo[3] = (_Float16)0.f;
+      char *p = smem + RAW_OFF + buf * RAW_BYTES + (r_row * RAWP + r_col) * 8;
+      *reinterpret_cast<h4 *>(p) = hi;
+      *reinterpret_cast<h4 *>(p + RAW_PLANE) = lo;
+    }
+  };
+  // ---- conv1_1 of tile `it` (raw patch it&1) into halo image it&1: all waves, groups wave and wave+8 together ----
+  auto conv1_1_halo = [&](int it) {
+    int n, x0, y0;
+    tile_coords(it, n, x0, y0);
+    char *slot = smem + (it & 1) * SLOT;
+    const char *rawp = smem + RAW_OFF + (it & 1) * RAW_BYTES;
+    constexpr int NU = (NGRP + 7) / 8;  // 2
+    f32x4 a1[NU][4];
+    int qv[NU], hyv[NU], hxv[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int q = (wave + 8 * u) * 16 + l15, qc = q < NQ ? q : NQ - 1;
+      qv[u] = q;
+      hyv[u] = qc / HWD;
+      hxv[u] = qc - hyv[u] * HWD;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)  // the accumulator starts at bias x scale
+        a1[u][i] = *reinterpret_cast<const f32x4 *>(smem + B1_OFF + (16 * i + 4 * c4) * 4);
+    }
+    const bool interior = y0 >= 1 && y0 + TH + 1 <= H && x0 >= 1 && x0 + TW + 1 <= W;  // (block-uniform)
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      u32x4 bh[NU], bl[NU];
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const char *rp = rawp + ((hyv[u] + 2 * m + (c4 >> 1)) * RAWP + hxv[u] + (c4 & 1) * 2) * 8;
+        const u32x2 h0 = *reinterpret_cast<const u32x2 *>(rp), h1 = *reinterpret_cast<const u32x2 *>(rp + 8);
+        const u32x2 l0 = *reinterpret_cast<const u32x2 *>(rp + RAW_PLANE), l1 = *reinterpret_cast<const u32x2 *>(rp + RAW_PLANE + 8);
+        bh[u] = (u32x4){h0[0], h0[1], h1[0], h1[1]};
+        bl[u] = (u32x4){l0[0], l0[1], l1[0], l1[1]};
+      }
+#pragma unroll
+      for (int term = 0; term < 3; ++term)  // w_hi*a_hi, w_lo*a_hi, w_hi*a_lo: consecutive MFMAs on different accumulators
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const u32x4 wfr = *reinterpret_cast<const u32x4 *>(
+              smem + W1_OFF + ((((i * 2 + m) * 2 + (term == 1 ? 1 : 0)) * 64 + lane) * 16));
+#pragma unroll
+          for (int u = 0; u < NU; ++u) {
+            if (wave + 8 * u < NGRP)  // (wave-uniform)
+              a1[u][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wfr),
+                                                                __builtin_bit_cast(f16x8, term == 2 ? bl[u] : bh[u]),
+                                                                a1[u][i], 0, 0, 0);
+          }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int q = qv[u];
+      const int gy = y0 - 1 + hyv[u], gx = x0 - 1 + hxv[u];
+      const bool inside = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      if (wave + 8 * u < NGRP && q < NQ) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {  // channels 16*i + 4*c4 .. +3: chunk i>>1, quarter 2*(i&1) + (c4>>1), half (c4&1)
+          h4 hi, lo;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float v = (interior || inside) ? fmaxf(a1[u][i][e] * w1inv, 0.f) : 0.f;
+            hi[e] = (_Float16)v;
+            lo[e] = (_Float16)(v - (float)hi[e]);
+          }
+          char *p = slot + (i >> 1) * CH_BYTES + q * PITCH + ((2 * (i & 1) + (c4 >> 1)) << 4) + (c4 & 1) * 8;
+          *reinterpret_cast<h4 *>(p) = hi;
+          *reinterpret_cast<h4 *>(p + LO) = lo;
+        }
+      }
+    }
+  };
+
+  const unsigned kOOB = 0x80000000u;
+  const unsigned img_out_bytes = (unsigned)H * (unsigned)W * (unsigned)COUT * 4u;
+  __syncthreads();  // zeroed patches, conv1_1 fragments and bias are in LDS
+  raw_fetch(0);
+  raw_commit(0);
+  raw_fetch(1);
+  raw_commit(1);
+  __syncthreads();
+  conv1_1_halo(0);
+  auto conv1_2_tile = [&](int it) {
+    int n, x0, y0;
+    tile_coords(it, n, x0, y0);
+    const char *slot = smem + (it & 1) * SLOT;
+    const __amdgpu_buffer_rsrc_t orsrc =
+        __builtin_amdgcn_make_buffer_rsrc(out + (size_t)n * H * W * COUT, 0, img_out_bytes, 0x00020000);
+    u32x4 bh[2][GPP], bl[2][GPP];
+    auto load_b = [&](const int (&q0)[GPP], int ks, u32x4(&h)[GPP], u32x4(&l)[GPP]) {
+      const int cc = ks / 9, t = ks - cc * 9, ky = t / 3, kx = t - ky * 3;
+#pragma unroll
+      for (int g = 0; g < GPP; ++g) {
+        h[g] = *reinterpret_cast<const u32x4 *>(slot + q0[g] + (cc * CH_BYTES + (ky * HWD + kx) * PITCH));
+        l[g] = *reinterpret_cast<const u32x4 *>(slot + q0[g] + (cc * CH_BYTES + (ky * HWD + kx) * PITCH + LO));
+      }
+    };
+    int q0[GPP];  // byte offset of this lane's hi fragment at tap (0,0), chunk 0, per 16-pixel group
+#pragma unroll
+    for (int g = 0; g < GPP; ++g) q0[g] = ((ph * RW) * HWD + g * 16 + l15) * PITCH + (c4 << 4);
+    asm volatile("" : "+v"(q0[0]), "+v"(q0[1]));
+#pragma unroll 1
+    for (int pass = 0; pass < NPASS; ++pass) {
+      f32x4 acc[3][GPP];  // hi*hi | w_lo*a_hi | w_hi*a_lo
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int g = 0; g < GPP; ++g) acc[i][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      load_b(q0, 0, bh[0], bl[0]);
+#pragma unroll
+      for (int ks = 0; ks < 18; ++ks) {
+        if (ks + 1 < 18) load_b(q0, ks + 1, bh[(ks + 1) & 1], bl[(ks + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int term = 0; term < 3; ++term)
+#pragma unroll
+          for (int g = 0; g < GPP; ++g)
+            acc[term][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                __builtin_bit_cast(f16x8, wf[term == 1 ? 1 : 0][ks]),
+                __builtin_bit_cast(f16x8, term == 2 ? bl[ks & 1][g] : bh[ks & 1][g]), acc[term][g], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int g = 0; g < GPP; ++g) {
+        const int gy = y0 + ph * RW + pass, gx = x0 + g * 16 + l15;
+        const bool inside = gy < H && gx < W;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          v[e] = fmaxf((acc[0][g][e] + (acc[1][g][e] + acc[2][g][e])) * winv2 + bia[e], 0.f);
+        const unsigned off = inside ? (unsigned)(((gy * W + gx) * COUT + cg * 16 + 4 * c4) * 4) : kOOB;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), orsrc, off, 0, 0);
+      }
+#pragma unroll
+      for (int g = 0; g < GPP; ++g) q0[g] += HWD * PITCH;  // next tile row
+      asm volatile("" : "+v"(q0[0]), "+v"(q0[1]));
+    }
+  };
+  for (int it = 0; it < my_tiles; ++it) {
+    __syncthreads();
+    raw_fetch(it + 2);  // lands under this tile's MFMAs
+    const bool next = it + 1 < my_tiles;
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {  // (a loop, so that each phase's code exists once)
+      if ((half == 0) == (wave < 4)) {
+        __builtin_amdgcn_s_setprio(0);
+        conv1_2_tile(it);
+      } else if (next) {
+        __builtin_amdgcn_s_setprio(2);
+        conv1_1_halo(it + 1);
+      }
+    }
+    raw_commit(it & 1);  // tile it+2's patch; patch it&1 was last read by conv1_1 of tile `it`, during tile it-1
+  }
+#endif
+}
+
+// ---------------------------------------------------------------------------------
 // conv1_1 + conv1_2 fused (16-bit modes): the whole of stage 1 without the 64-channel
 // full-resolution intermediate ever touching HBM.
 // ---------------------------------------------------------------------------------
@@ -2128,6 +2391,37 @@ static int launch_conv1_regw(const float *x, const float *y, int B, int n, int H
                                                       reinterpret_cast<typename P::T *>(out), H, W, tiles_x, tiles_y,
                                                       total, w1inv);
   return check_launch("conv1_regw");
+}
+
+int conv1_fused_split(const float *x, const float *y, int B, int n, int H, int W, const void *packed_v, void *out,
+                      hipStream_t st) {
+  const char *packed = static_cast<const char *>(packed_v);
+  constexpr int LDS = 2 * 2 * 208 * 160 + 2 * 2 * 9 * 40 * 8 + 2 * 4 * 2 * 64 * 16 + 256;  // 161 280
+  static std::atomic<bool> attr_done_dev[64];
+  std::atomic<bool> &attr_done = attr_done_dev[current_device() & 63];
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv1_regw_split_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+      set_error("conv1_regw_split: cannot raise the dynamic LDS limit to %d bytes", LDS);
+      return NQA_E_LAUNCH;
+    }
+    attr_done = true;
+  }
+  const int cus = num_cus();
+  if (!cus) {
+    set_error("conv1_regw_split: cannot query the device");
+    return NQA_E_LAUNCH;
+  }
+  const int tiles_x = cdiv(W, 32), tiles_y = cdiv(H, 4), total = n * tiles_x * tiles_y;
+  const int grid = total < cus ? total : cus;
+  const float *b1 = reinterpret_cast<const float *>(packed + layer_bias_offset(0, NQA_PREC_F32S));
+  const float *b2 = reinterpret_cast<const float *>(packed + layer_bias_offset(1, NQA_PREC_F32S));
+  const float *w1inv = reinterpret_cast<const float *>(packed + layer0_mfma_offset(NQA_PREC_F32S));
+  TimedLaunch t(NQA_K_CONV, st);
+  conv1_regw_split_kernel<<<grid, 512, LDS, st>>>(x, y, B, packed + layer0_m16_offset(NQA_PREC_F32S), b1,
+                                                  packed + regw_offset(1, NQA_PREC_F32S), b2,
+                                                  static_cast<float *>(out), H, W, tiles_x, tiles_y, total, w1inv);
+  return check_launch("conv1_regw_split");
 }
 
 // stage 1 (conv1_1 + conv1_2) of images [x(0..B), y(0..n-B)) in one kernel; 16-bit modes only

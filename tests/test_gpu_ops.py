@@ -90,6 +90,36 @@ def test_conv1_fused(stage1, prec, shape, np_convs, packed, dev):
     _close(got, ref, 3 * OUT_RTOL[prec], f"conv1_fused[{prec}] {shape}")
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 5, 7), (1, 3, 4, 32), (1, 3, 9, 33), (3, 3, 37, 70), (1, 3, 64, 100),
+                                   (1, 3, 130, 95), (2, 3, 1, 1), (1, 3, 3, 200)], ids=lambda s: "x".join(map(str, s)))
+def test_f32s_stage1_fused(shape, np_convs, packed, dev):
+    """f32s stage 1 in one kernel (conv1_regw_split_kernel: conv1_1 on MFMA with three-term products feeding a three-term
+    conv1_2 through LDS, 4 x 32 tiles) == the two convolutions in float64, to float32-class accuracy, at ragged sizes
+    (partial tiles in both directions, frames smaller than a tile, more tiles than CUs), and == the round-2 pair of
+    kernels (first-forms bit of nqa_set_conv_variant) to the rounding of another summation order."""
+    from nerf_qa_amd import ops
+    x = _rand(shape, 77)
+    mean = torch.tensor([0.485, 0.456, 0.406], dtype=torch.float64).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225], dtype=torch.float64).view(1, 3, 1, 1)
+    w0, b0 = torch.from_numpy(np_convs[0][0]).double(), torch.from_numpy(np_convs[0][1]).double()
+    w1, b1 = torch.from_numpy(np_convs[1][0]).double(), torch.from_numpy(np_convs[1][1]).double()
+    ref = F.relu(F.conv2d(F.relu(F.conv2d((x.double() - mean) / std, w0, b0, padding=1)), w1, b1, padding=1))
+    got = {}
+    for name, variant in (("fused", ops.DEFAULT_CONV_VARIANT), ("pair", ops.DEFAULT_CONV_VARIANT | 16)):
+        ops.set_conv_variant(variant)
+        try:
+            tap1 = ops.vgg_pyramid(x.to(dev), packed["f32s"], "f32s")[0]
+        finally:
+            ops.set_conv_variant(ops.DEFAULT_CONV_VARIANT)
+        assert tap1.dtype == torch.float32 and tap1.shape == (shape[0], shape[2], shape[3], 64)
+        got[name] = tap1.permute(0, 3, 1, 2).double().cpu()
+        assert torch.isfinite(got[name]).all()
+    scale = ref.abs().max().item()
+    e_f, e_p = (got["fused"] - ref).abs().max().item() / scale, (got["pair"] - ref).abs().max().item() / scale
+    print(f"\n f32s stage 1 {shape}: fused {e_f:.2e}, two kernels {e_p:.2e} of the largest activation")
+    assert e_f <= 2e-6 and e_p <= 2e-6, (shape, e_f, e_p)
+
+
 def test_conv1_fused_rejects_f32(packed, dev):
     from nerf_qa_amd import NqaError, ops
     with pytest.raises(NqaError):
