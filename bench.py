@@ -157,8 +157,9 @@ def rooflines(ktimes, h, w, b, prec, traffic):
     peak = PEAK_F32_TFLOPS if prec == "f32" else PEAK_F16_TFLOPS
     roof = {
         "kernel": "VGG conv layers 1..12 on MFMA: conv1_regw_kernel (stage 1), conv3x3_regw_kernel / conv3x3_regw128_kernel "
-                  "(conv2_1 / conv2_2, conv3_1), conv3x3_igemm_kernel (the rest; all layers in f32 / f32s; f32m: the "
-                  "two-term instances of the first three for layers 1..4, two-term igemm for 5..6, f32s igemm for 7..12)",
+                  "(conv2_1 / conv2_2, conv3_1), conv3x3_igemm_kernel (the rest; all layers in f32; f32s: conv1_regw_split_kernel "
+                  "for stage 1, igemm behind; f32m: the two-term instances of the first three for layers 1..4, two-term "
+                  "igemm for 5..6, f32s igemm for 7..12)",
         "bound": "mfma", "achieved": round(ach, 2) if ach else None, "peak": peak, "unit": "TFLOP/s",
         "frac": round(ach / peak, 4) if ach else None,
         "traffic": traffic.get("conv"), "traffic_source": traffic.get("_source"),

@@ -32,7 +32,7 @@ if [ "$WHAT" != "trace" ]; then
       echo "pmc $C $wl $pr done" >> $R/gpurun_out/prof_r3.progress
     done
   done
-  for W in 1080p:f16w 1080p:f16 1080p:f32m 256:f16w; do
+  for W in 1080p:f16w 1080p:f16 1080p:f32m 1080p:f32s 256:f16w; do
     wl=${W%%:*}; pr=${W##*:}
     rm -rf $OUT/pmc_mfma_${wl}_${pr}
     rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma_${wl}_${pr} -- python3 $R/bench.py --workload $wl --precision $pr --steps 2 --warmup 1 --only --no-cpu-baseline > /dev/null 2> $OUT/pmc_mfma_${wl}_${pr}.err

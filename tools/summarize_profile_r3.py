@@ -11,7 +11,7 @@ src, dst = sys.argv[1], sys.argv[2]
 os.makedirs(dst, exist_ok=True)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CONV = ("conv3x3_igemm_kernel", "conv3x3_regw_kernel", "conv3x3_regw128_kernel", "conv1_regw_kernel", "conv1_fused_kernel",
-        "conv1_tile_kernel")
+        "conv1_tile_kernel", "conv1_regw_split_kernel")
 
 
 def short(name):
