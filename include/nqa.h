@@ -100,9 +100,10 @@ int nqa_pack_vgg_weights(const float *const w_host[NQA_NUM_CONVS], const float *
 int nqa_conv1_1(const float *x_nchw, int n, int H, int W, const void *packed_w, int prec, void *out_nhwc,
                 void *stream);
 
-/* Stage 1 in one kernel (16-bit modes only): conv1_1 as above followed by conv1_2+ReLU
+/* Stage 1 in one kernel (16-bit modes and NQA_PREC_F32S): conv1_1 as above followed by conv1_2+ReLU
  * (features[0..3], DISTS_pt.py:36-37), the 64-channel intermediate staying in LDS.
- * x: dev float32 NCHW (n,3,H,W); out: dev NHWC (n,H,W,64) = relu1_2. */
+ * x: dev float32 NCHW (n,3,H,W); out: dev NHWC (n,H,W,64) = relu1_2 in prec's element type (float in NQA_PREC_F32S, whose
+ * products are three-term (hi, lo) splits in both convolutions).  NQA_PREC_F32 has no fused form. */
 int nqa_conv1_fused(const float *x_nchw, int n, int H, int W, const void *packed_w, int prec, void *out_nhwc,
                     void *stream);
 
@@ -209,7 +210,8 @@ int nqa_resize_pil_bilinear_u8(const uint8_t *in, int n, int Hin, int Win, int H
  * layer, 1 (default) = + 8-wave 256 ch x 256 px tiles on layers with >= 256 output channels, 2 =
  * + 8-wave 128 ch x 512 px tiles wherever the map is large enough (measured equal to 1).
  * Adding 4 selects the tile form of the fused stage-1 kernel; adding 16 selects the round-1 forms of stage 1 (the
- * persistent two-phase kernel) and of conv2_1 (the implicit GEMM) instead of the register-resident-weights kernels,
+ * persistent two-phase kernel) and of conv2_1 (the implicit GEMM) instead of the register-resident-weights kernels, and
+ * in NQA_PREC_F32S the round-2 pair of stage-1 kernels (VALU conv1_1 + implicit-GEMM conv1_2) instead of the fused one,
  * adding 32 the implicit GEMM for conv2_2 / conv3_1;
  * adding 8 selects the first form of the A-DISTS window pass (every wave loads its own taps instead of sharing them
  * through LDS).  Results agree in every variant to the rounding of a different summation order inside a layer (the

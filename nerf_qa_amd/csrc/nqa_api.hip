@@ -613,6 +613,7 @@ int nqa_conv1_fused(const float *x, int n, int H, int W, const void *packed, int
     return NQA_E_ARG;
   }
   if (bad_dims("conv1_fused", n, H, W, prec, 64)) return NQA_E_ARG;
+  if (prec == NQA_PREC_F32S) return conv1_fused_split(x, nullptr, n, n, H, W, packed, out, static_cast<hipStream_t>(stream));
   return conv1_fused(x, nullptr, n, n, H, W, packed, prec, out, static_cast<hipStream_t>(stream));
 }
 

@@ -100,7 +100,7 @@ def conv1_1(x: torch.Tensor, packed: torch.Tensor, prec) -> torch.Tensor:
 
 
 def conv1_fused(x: torch.Tensor, packed: torch.Tensor, prec) -> torch.Tensor:
-    """relu1_2 (NHWC) straight from the image: conv1_1 + conv1_2 in one kernel (16-bit modes)."""
+    """relu1_2 (NHWC) straight from the image: conv1_1 + conv1_2 in one kernel (16-bit modes and "f32s": float out)."""
     p = prec_id(prec)
     dev = _need_cuda(x, packed)
     x = _f32c(x)

@@ -114,6 +114,8 @@ def test_f32s_stage1_fused(shape, np_convs, packed, dev):
         assert tap1.dtype == torch.float32 and tap1.shape == (shape[0], shape[2], shape[3], 64)
         got[name] = tap1.permute(0, 3, 1, 2).double().cpu()
         assert torch.isfinite(got[name]).all()
+    op = ops.conv1_fused(x.to(dev), packed["f32s"], "f32s")  # the single-operator entry point: the same kernel
+    assert op.dtype == torch.float32 and torch.equal(op.permute(0, 3, 1, 2).double().cpu(), got["fused"])
     scale = ref.abs().max().item()
     e_f, e_p = (got["fused"] - ref).abs().max().item() / scale, (got["pair"] - ref).abs().max().item() / scale
     print(f"\n f32s stage 1 {shape}: fused {e_f:.2e}, two kernels {e_p:.2e} of the largest activation")
