@@ -242,7 +242,9 @@ def make_model(metric, precision, dev, h, w):
         net = ADISTS(precision=precision, vgg16_path=VGG).to(dev).eval()
         return (lambda a, b: net(a, b, as_loss=False)), net.precision_for(h, w), net.vgg_source  # x = reference frame
     net = DISTS(precision=precision, vgg16_path=VGG).to(dev).eval()
-    prec = net.precision_for(h, w)  # "auto" (the default) calibrates f16 against f32s with these weights, once
+    # "auto" (the default) calibrates every rung against f32s with these weights, once per frame-size class; under a
+    # process group all ranks then run the most accurate rung any of them chose (one mode per video whatever N)
+    prec = sharding.agree_precision(net, h, w, dev)
     if net.precision == "auto":
         AUTO_REPORT.update({k: (round(v, 9) if isinstance(v, float) else v) for k, v in net.calibrate(dev, h, w).items()})
     return net, prec, net.vgg_source

@@ -50,3 +50,24 @@ def score_frames_sharded(score_batch: Callable[[int, int], torch.Tensor], n_fram
         parts.append(score_batch(s, min(hi, s + batch)).reshape(-1).float())
     local = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.float32, device=device)
     return gather_scores(local, n_frames, group)
+
+
+def agree_precision(model, h: int, w: int, device, group=None) -> str:
+    """DISTS `auto` under a process group: every rank calibrates on its own GPU (the measurement is deterministic, but
+    two GPUs may land on different sides of a threshold), then ALL ranks adopt the most accurate rung any rank chose, so
+    the frames of one video are scored in one mode whatever the world size.  Returns the mode frames of h x w run in;
+    a module with a named precision, or no process group, is returned as it is."""
+    prec = model.precision_for(h, w, device)
+    if getattr(model, "precision", None) != "auto" or not (dist.is_available() and dist.is_initialized()):
+        return prec
+    from .DISTS_pytorch.DISTS_pt import AUTO_MIN_PIXELS, LADDER
+    if h * w < AUTO_MIN_PIXELS:
+        return prec  # always f32s, nothing to agree on
+    t = torch.tensor([LADDER.index(prec)], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)  # LADDER is ordered fastest -> most accurate
+    agreed = LADDER[int(t.item())]
+    report = model.calibrate(device, h, w)  # (the cached report of this size class: what precision_for reads)
+    if agreed != prec:
+        report["choice_local"], report["choice"] = prec, agreed
+    report["agreed_over_ranks"] = dist.get_world_size(group)
+    return agreed

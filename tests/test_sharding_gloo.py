@@ -125,3 +125,50 @@ def test_synthetic_video_sharded_world2(n_frames, batch):
         assert (lo, hi) == (min(n_frames, rank * per), min(n_frames, (rank + 1) * per)) or not seen
     cols = video.video_columns("DISTS", results[0][1])
     assert cols["DISTS"].dtype == np.float32 and abs(float(cols["DISTS"]) - float(np.mean(want))) < 1e-7
+
+
+def _agree_worker(rank, world, port, choices, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nerf_qa_amd import sharding
+
+    class Model:  # what agree_precision touches of a DISTS module: its calibration report of the frame's size class
+        precision = "auto"
+
+        def __init__(self, choice):
+            self.report = {"choice": choice}
+
+        def precision_for(self, h, w, device=None):
+            return "f32s" if h * w < 96 * 96 else self.report["choice"]
+
+        def calibrate(self, device, h, w):
+            return self.report
+
+    m = Model(choices[rank])
+    got = sharding.agree_precision(m, 1080, 1920, torch.device("cpu"))
+    small = sharding.agree_precision(m, 64, 64, torch.device("cpu"))
+    named = Model(choices[rank])
+    named.precision = "f16"
+    q.put((rank, got, m.precision_for(1080, 1920), m.report, small, sharding.agree_precision(named, 1080, 1920, torch.device("cpu"))))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("choices,want", [(("f16", "f32m"), "f32m"), (("f32s", "f16w"), "f32s"), (("f16", "f16"), "f16")])
+def test_ranks_agree_on_the_most_accurate_auto_choice(choices, want):
+    """bench.py --gpus N / the video harness: one precision mode per video whatever each rank's own calibration said."""
+    world = len(choices)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_agree_worker, args=(r, world, port, choices, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, got, after, report, small, named in results:
+        assert got == want and after == want and report["agreed_over_ranks"] == world
+        assert report.get("choice_local", want) == choices[rank]
+        assert small == "f32s" and named == choices[rank]  # nothing to agree on: tiny frames, named precision
