@@ -28,7 +28,7 @@ def models(dev):
         m = {"f16": DISTS(precision="f16").to(dev).eval(), "f32": DISTS(precision="f32").to(dev).eval(),
              "a16": ADISTS(precision="f16").to(dev).eval(), "a32": ADISTS(precision="f32").to(dev).eval(),
              "a32s": ADISTS(precision="f32s").to(dev).eval(), "f32s": DISTS(precision="f32s").to(dev).eval()}
-        # the shipped defaults: DISTS "auto" = f32s below 96x96 pixels and, above, the fastest mode the one-time
+        # the shipped defaults: DISTS "auto" = f32s below 128x128 pixels and, above, the fastest mode the one-time
         # calibration of the module's VGG weights admits for the frame-size class (the gain-1.0 stand-ins: f16w below
         # 224x224 pixels, plain f16 from there up); A-DISTS auto = f32 / f32s by size
         d = DISTS().to(dev)

@@ -140,7 +140,7 @@ def _agree_worker(rank, world, port, choices, q):
             self.report = {"choice": choice}
 
         def precision_for(self, h, w, device=None):
-            return "f32s" if h * w < 96 * 96 else self.report["choice"]
+            return "f32s" if h * w < 128 * 128 else self.report["choice"]
 
         def calibrate(self, device, h, w):
             return self.report

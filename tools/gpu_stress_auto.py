@@ -1,4 +1,4 @@
-"""The shipped default (`auto`) against f32s on random frame sizes from 96x96 to 1080p, per stand-in weight gain and per
+"""The shipped default (`auto`) against f32s on random frame sizes from 128x128 to 1080p, per stand-in weight gain and per
 calibration size class (GPU box): how far the modes the calibration admits really stray on frames it has not seen.
 f32s itself sits within 1e-6 of the CPU oracle (tests/test_gpu_fullsize_golden.py), so the deviation from f32s IS the
 deviation from the reference to that accuracy.  Content differs from the calibration's generator on purpose: random
@@ -56,7 +56,7 @@ for gain in GAINS:
     rng = np.random.default_rng(777)
     g = torch.Generator(device=dev).manual_seed(31337)
     per = {}
-    lo, hi = math.log(96 * 96), math.log(1080 * 1920)
+    lo, hi = math.log(128 * 128), math.log(1080 * 1920)
     for i in range(N):
         area = math.exp(rng.uniform(lo, hi))
         aspect = math.exp(rng.uniform(-0.7, 0.7))
