@@ -990,9 +990,10 @@ __global__ __launch_bounds__(512) void conv1_regw_kernel(const float *__restrict
   // ds_read_b128 of 16 consecutive pixels at one 16-byte quarter is bank-conflict-free WITHOUT an XOR swizzle (the
   // image is written by ds_write here, not by 1-KB LDS-DMA pieces, so the pitch is free), and then a tap is a
   // compile-time byte offset from one per-group base register: no address arithmetic in the k loop.
-  constexpr int PITCH = 96, CH_BYTES = 352 * PITCH, SLOT = 2 * CH_BYTES;
+  constexpr int PITCH = 96, CH_BYTES = NQ * PITCH, SLOT = 2 * CH_BYTES;  // (the last record either convolution touches: 339)
   constexpr int RAWP = 40, RAW_ROWS = 13, RAW_BYTES = RAW_ROWS * RAWP * 8;  // (+1 row read, with zero weights, by MFMA 1)
   constexpr int RAW_OFF = 2 * SLOT, W1_OFF = RAW_OFF + 2 * RAW_BYTES, B1_OFF = W1_OFF + NTERM * 4 * 2 * 64 * 16;  // two raw patches
+  constexpr int STG_OFF = B1_OFF + 256;  // float staging of the raw pixels, [3 planes][512 threads] (filled by LDS-DMA)
   constexpr int CW = 32 / NTERM, NG = COUT / CW;  // channels per wave, channel groups (2 of 32 | 4 of 16)
   constexpr int RW = NG, GPP = 2, NPASS = 2 * RW / GPP;
   constexpr int NGRP = (NQ + 15) / 16;  // 22 groups of 16 halo pixels
@@ -1038,33 +1039,52 @@ __global__ __launch_bounds__(512) void conv1_regw_kernel(const float *__restrict
   for (int i = tid; i < 2 * RAW_BYTES / 8; i += 512) reinterpret_cast<u32x2 *>(smem + RAW_OFF)[i] = (u32x2){0u, 0u};
 
   // ---- raw patch: thread t < 432 owns pixel (t / 36, t % 36) of the 12 x 36 patch ----
+  // The three float planes of a pixel travel by LDS-DMA into a staging area ([plane][thread], one dword per lane) when
+  // the tile starts and are normalised into the raw patch a phase later (raw_commit): nothing waits on them in between.
+  // As plain loads they did: hipcc hoisted `pixel - mean` to right behind the loads, and with the consumer moved away
+  // it still drained vmcnt(0) in front of the phase loop (a store-only loop that uses a value loaded outside it), so
+  // every wave sat out an HBM round trip per tile -- 230 us of a 2 580 us launch at 1080p (timing build without the
+  // loads: 2 350 us).  The DMA is retired by hand with a counted vmcnt, as everywhere else in this file.
   const int r_row = tid / 36, r_col = tid - r_row * 36;
   const bool r_mine = tid < 12 * 36;
   const float mean[3] = {0.485f, 0.456f, 0.406f};
   const float sd[3] = {0.229f, 0.224f, 0.225f};
-  float rv[3];
   bool r_ok = false;
   auto raw_fetch = [&](int it) {
     r_ok = false;
-    rv[0] = rv[1] = rv[2] = 0.f;
-    if (it < my_tiles && r_mine) {
+#ifdef NQA_R_NO_RAW  // timing-only ablation: no raw pixel loads at all (results are wrong on purpose)
+    return;
+#endif
+    if (it < my_tiles) {  // (block-uniform; every wave issues its three pieces, so the counted waits below hold)
       int n, x0, y0;
       tile_coords(it, n, x0, y0);
       const int gy = y0 - 2 + r_row, gx = x0 - 2 + r_col;
-      r_ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-      if (r_ok) {
-        const float *img = (n < B ? x + (size_t)n * 3 * HW : y + (size_t)(n - B) * 3 * HW) + gy * W + gx;
-        rv[0] = img[0];
-        rv[1] = img[HW];
-        rv[2] = img[2 * HW];
-      }
+      r_ok = r_mine && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      const float *img = n < B ? x + (size_t)n * 3 * HW : y + (size_t)(n - B) * 3 * HW;
+      const __amdgpu_buffer_rsrc_t rsrc =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(img), 0, 3u * (unsigned)HW * 4u, 0x00020000);
+      const unsigned off = r_ok ? (unsigned)((gy * W + gx) * 4) : 0x80000000u;
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t *)(smem + STG_OFF + c * 2048 + wave * 256), 4, off,
+                                                 c * HW * 4, 0, 0);
     }
   };
-  auto raw_commit = [&](int buf) {
+  // `younger`: VMEM operations this wave has issued since raw_fetch (they retire in order): the 8 stores of conv1_2
+  // for the waves that run it before conv1_1, none otherwise
+  static_assert((2 / NTERM) * GPP * NPASS == 8, "raw_commit's counted wait assumes 8 stores per wave and tile");
+  auto raw_commit = [&](int buf, bool stores_since) {
+    if (stores_since)
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (r_mine) {
       t4 v;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) v[c] = P::from_f(r_ok ? (rv[c] - mean[c]) / sd[c] : 0.f);
+      for (int c = 0; c < 3; ++c) {
+        const float raw = *reinterpret_cast<const float *>(smem + STG_OFF + (c * 512 + tid) * 4);
+        v[c] = P::from_f(r_ok ? (raw - mean[c]) / sd[c] : 0.f);
+      }
       v[3] = P::from_f(0.f);
       *reinterpret_cast<t4 *>(smem + RAW_OFF + buf * RAW_BYTES + (r_row * RAWP + r_col) * 8) = v;
     }
@@ -1145,9 +1165,9 @@ __global__ __launch_bounds__(512) void conv1_regw_kernel(const float *__restrict
   // order, so the latency-bound conv1_1 of one runs beside the MFMA-bound conv1_2 of the other.
   __syncthreads();  // zeroed patches, conv1_1 fragments and bias are in LDS
   raw_fetch(0);
-  raw_commit(0);
+  raw_commit(0, false);
   raw_fetch(1);
-  raw_commit(1);
+  raw_commit(1, false);
   __syncthreads();
   conv1_1_halo(0);
   auto conv1_2_tile = [&](int it) {
@@ -1223,32 +1243,61 @@ __global__ __launch_bounds__(512) void conv1_regw_kernel(const float *__restrict
       asm volatile("" : "+v"(q0[0]), "+v"(q0[1]));
     }
   };
+#ifdef NQA_STAMPS  // per wave: [0] barrier wait, [1] conv1_2 k-loops + epilogue, [2] conv1_1, [3] raw fetch + commit
+  unsigned long long seg_sum[4] = {0, 0, 0, 0};
+#endif
   for (int it = 0; it < my_tiles; ++it) {
+    NQA_STAMP(s0);
     __syncthreads();
+    NQA_STAMP(s1);
+    NQA_STAMP_ADD(0, s0, s1);
     raw_fetch(it + 2);  // lands under this tile's MFMAs
+    NQA_STAMP(s2);
+    NQA_STAMP_ADD(3, s1, s2);
     const bool next = it + 1 < my_tiles;
 #if defined(NQA_R_NO_P1)  // timing-only ablations (tools/gpu_fused_bench.py; results are wrong on purpose)
     conv1_2_tile(it);
     (void)next;
+    raw_commit(it & 1, true);
 #elif defined(NQA_R_NO_P2)
     if (next) conv1_1_halo(it + 1);
+    raw_commit(it & 1, false);
 #else
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {  // (a loop, so that each phase's code exists once)
       // conv1_1 is a latency chain (LDS read -> 8 MFMAs -> convert -> LDS write, three groups in flight): at a
       // higher issue priority its few instructions go out the moment they are ready and the partner wave's
       // conv1_2 fills every other slot (2.70 -> 2.59 ms at 1080p, 409 -> 386 us at 256 x 256; priority 3: 2.65)
+      NQA_STAMP(h0);
       if ((half == 0) == (wave < 4)) {
         __builtin_amdgcn_s_setprio(0);
         conv1_2_tile(it);
-      } else if (next) {
-        __builtin_amdgcn_s_setprio(2);
-        conv1_1_halo(it + 1);
+        NQA_STAMP(h1);
+        NQA_STAMP_ADD(1, h0, h1);
+      } else {
+        if (next) {
+          __builtin_amdgcn_s_setprio(2);
+          conv1_1_halo(it + 1);
+        }
+        NQA_STAMP(h1);
+        NQA_STAMP_ADD(2, h0, h1);
+        // tile it+2's patch (patch it&1 was last read by conv1_1 of tile `it`, during tile it-1), committed right behind
+        // this wave's conv1_1 phase: the pixels were requested a phase ago, and the wave's youngest stores are a phase
+        // old too (waves 0-3: this tile's conv1_2; waves 4-7: the previous tile's), so the wait in front of it is short
+        raw_commit(it & 1, wave < 4);
+        NQA_STAMP(h2);
+        NQA_STAMP_ADD(3, h1, h2);
       }
     }
 #endif
-    raw_commit(it & 1);  // tile it+2's patch; patch it&1 was last read by conv1_1 of tile `it`, during tile it-1
   }
+#ifdef NQA_STAMPS
+  if (lane == 0) {
+    for (int i = 0; i < 4; ++i) atomicAdd(&g_stamps[i], seg_sum[i]);
+    atomicAdd(&g_stamps[4], (unsigned long long)my_tiles);
+    if (wave < 4) atomicAdd(&g_stamps[5], seg_sum[1]); else atomicAdd(&g_stamps[6], seg_sum[1]);
+  }
+#endif
 #endif
 }
 
@@ -1269,7 +1318,8 @@ __global__ __launch_bounds__(512) void conv1_regw_kernel(const float *__restrict
 //     VGPRs, the two-term blob format), three accumulators per 16-pixel group (hi*hi | lo_w*hi_a | hi_w*lo_a) summed in
 //     the epilogue; float NHWC out (the tap the statistics and the pool read).
 // Same pipeline as conv1_regw_kernel: one barrier per tile, the two waves of a SIMD take conv1_1 (of the next tile) and
-// conv1_2 (of this one) in opposite order.  LDS: 2 x 66 560 (halo) + 2 x 5 760 (raw) + 16 384 (conv1_1 fragments) + 256.
+// conv1_2 (of this one) in opposite order.  LDS: 2 x 65 280 (halo) + 2 x 5 760 (raw) + 16 384 (conv1_1 fragments) + 256
+// (bias) + 3 840 (raw-pixel staging) = 162 560 of the 163 840 bytes.
 __global__ __launch_bounds__(512) void conv1_regw_split_kernel(const float *__restrict__ x, const float *__restrict__ y,
                                                                int B, const char *__restrict__ w1m,
                                                                const float *__restrict__ bias1,
@@ -1280,10 +1330,11 @@ __global__ __launch_bounds__(512) void conv1_regw_split_kernel(const float *__re
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef __attribute__((ext_vector_type(4))) _Float16 h4;
   constexpr int COUT = 64, TH = 4, TW = 32, HWD = TW + 2, NQ = (TH + 2) * HWD;  // 204 halo pixels
-  constexpr int NGRP = (NQ + 15) / 16, NQP = NGRP * 16;                         // 13 groups of 16, 208 records
-  constexpr int PITCH = 160, LO = 64, CH_BYTES = NQP * PITCH, SLOT = 2 * CH_BYTES;
+  constexpr int NGRP = (NQ + 15) / 16;                                          // 13 groups of 16
+  constexpr int PITCH = 160, LO = 64, CH_BYTES = NQ * PITCH, SLOT = 2 * CH_BYTES;  // (last record touched: 203)
   constexpr int RAWP = 40, RAW_ROWS = 9, RAW_PLANE = RAW_ROWS * RAWP * 8, RAW_BYTES = 2 * RAW_PLANE;  // hi plane, lo plane
   constexpr int RAW_OFF = 2 * SLOT, W1_OFF = RAW_OFF + 2 * RAW_BYTES, B1_OFF = W1_OFF + 2 * 4 * 2 * 64 * 16;
+  constexpr int STG_OFF = B1_OFF + 256, STG_T = 320;  // float staging of the raw pixels, [3 planes][waves 0..4] (LDS-DMA)
   constexpr int NG = 4, RW = 2, GPP = 2, NPASS = RW;  // 4 channel groups of 16; a wave: 2 rows x 2 groups of 16 columns
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [halo 0][halo 1][raw 0][raw 1][conv1_1 fragments][bias1]
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1324,35 +1375,42 @@ __global__ __launch_bounds__(512) void conv1_regw_split_kernel(const float *__re
   if (tid < 64) reinterpret_cast<float *>(smem + B1_OFF)[tid] = bias1[tid] / w1inv;  // (exact: a power of two)
   for (int i = tid; i < 2 * RAW_BYTES / 8; i += 512) reinterpret_cast<u32x2 *>(smem + RAW_OFF)[i] = (u32x2){0u, 0u};
 
-  // ---- raw patch: thread t < 288 owns pixel (t / 36, t % 36) of the 8 x 36 patch ----
+  // ---- raw patch: thread t < 288 owns pixel (t / 36, t % 36) of the 8 x 36 patch; the float planes arrive by LDS-DMA
+  // into a staging area and are normalised a phase later (see conv1_regw_kernel) ----
   const int r_row = tid / 36, r_col = tid - r_row * 36;
   const bool r_mine = tid < 8 * 36;
   const float mean[3] = {0.485f, 0.456f, 0.406f};
   const float sd[3] = {0.229f, 0.224f, 0.225f};
-  float rv[3];
   bool r_ok = false;
   auto raw_fetch = [&](int it) {
     r_ok = false;
-    rv[0] = rv[1] = rv[2] = 0.f;
-    if (it < my_tiles && r_mine) {
+    if (it < my_tiles && wave < STG_T / 64) {  // (wave-uniform: waves 0..4 hold the patch's 288 threads)
       int n, x0, y0;
       tile_coords(it, n, x0, y0);
       const int gy = y0 - 2 + r_row, gx = x0 - 2 + r_col;
-      r_ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-      if (r_ok) {
-        const float *img = (n < B ? x + (size_t)n * 3 * HW : y + (size_t)(n - B) * 3 * HW) + gy * W + gx;
-        rv[0] = img[0];
-        rv[1] = img[HW];
-        rv[2] = img[2 * HW];
-      }
+      r_ok = r_mine && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      const float *img = n < B ? x + (size_t)n * 3 * HW : y + (size_t)(n - B) * 3 * HW;
+      const __amdgpu_buffer_rsrc_t rsrc =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(img), 0, 3u * (unsigned)HW * 4u, 0x00020000);
+      const unsigned off = r_ok ? (unsigned)((gy * W + gx) * 4) : 0x80000000u;
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t *)(smem + STG_OFF + c * (STG_T * 4) + wave * 256), 4,
+                                                 off, c * HW * 4, 0, 0);
     }
   };
-  auto raw_commit = [&](int buf) {
+  static_assert(GPP * NPASS == 4, "raw_commit's counted wait assumes 4 stores per wave and tile");
+  auto raw_commit = [&](int buf, bool stores_since) {
+    if (stores_since)
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (r_mine) {
       h4 hi, lo;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        const float v = r_ok ? (rv[c] - mean[c]) / sd[c] : 0.f;
+        const float raw = *reinterpret_cast<const float *>(smem + STG_OFF + (c * STG_T + tid) * 4);
+        const float v = r_ok ? (raw - mean[c]) / sd[c] : 0.f;
         hi[c] = (_Float16)v;
         lo[c] = (_Float16)(v - (float)hi[c]);
       }
@@ -1435,9 +1493,9 @@ __global__ __launch_bounds__(512) void conv1_regw_split_kernel(const float *__re
   const unsigned img_out_bytes = (unsigned)H * (unsigned)W * (unsigned)COUT * 4u;
   __syncthreads();  // zeroed patches, conv1_1 fragments and bias are in LDS
   raw_fetch(0);
-  raw_commit(0);
+  raw_commit(0, false);
   raw_fetch(1);
-  raw_commit(1);
+  raw_commit(1, false);
   __syncthreads();
   conv1_1_halo(0);
   auto conv1_2_tile = [&](int it) {
@@ -1505,12 +1563,14 @@ __global__ __launch_bounds__(512) void conv1_regw_split_kernel(const float *__re
       if ((half == 0) == (wave < 4)) {
         __builtin_amdgcn_s_setprio(0);
         conv1_2_tile(it);
-      } else if (next) {
-        __builtin_amdgcn_s_setprio(2);
-        conv1_1_halo(it + 1);
+      } else {
+        if (next) {
+          __builtin_amdgcn_s_setprio(2);
+          conv1_1_halo(it + 1);
+        }
+        raw_commit(it & 1, wave < 4);  // tile it+2's patch, right behind this wave's conv1_1 phase (see conv1_regw_kernel)
       }
     }
-    raw_commit(it & 1);  // tile it+2's patch; patch it&1 was last read by conv1_1 of tile `it`, during tile it-1
   }
 #endif
 }
@@ -2363,7 +2423,7 @@ static int launch_conv1_tile(const float *x, const float *y, int B, int n, int H
 template <typename P, int NTERM = 1>
 static int launch_conv1_regw(const float *x, const float *y, int B, int n, int H, int W, const char *packed, void *out,
                              hipStream_t st, int blob_prec = P::ID) {
-  constexpr int LDS = 2 * 2 * 352 * 96 + 2 * 13 * 40 * 8 + NTERM * 4 * 2 * 64 * 16 + 256;
+  constexpr int LDS = 2 * 2 * 340 * 96 + 2 * 13 * 40 * 8 + NTERM * 4 * 2 * 64 * 16 + 256 + 3 * 512 * 4;
   static std::atomic<bool> attr_done_dev[64];
   std::atomic<bool> &attr_done = attr_done_dev[current_device() & 63];
   if (!attr_done) {
@@ -2396,7 +2456,7 @@ static int launch_conv1_regw(const float *x, const float *y, int B, int n, int H
 int conv1_fused_split(const float *x, const float *y, int B, int n, int H, int W, const void *packed_v, void *out,
                       hipStream_t st) {
   const char *packed = static_cast<const char *>(packed_v);
-  constexpr int LDS = 2 * 2 * 208 * 160 + 2 * 2 * 9 * 40 * 8 + 2 * 4 * 2 * 64 * 16 + 256;  // 161 280
+  constexpr int LDS = 2 * 2 * 204 * 160 + 2 * 2 * 9 * 40 * 8 + 2 * 4 * 2 * 64 * 16 + 256 + 3 * 320 * 4;  // 162 560
   static std::atomic<bool> attr_done_dev[64];
   std::atomic<bool> &attr_done = attr_done_dev[current_device() & 63];
   if (!attr_done) {
