@@ -1258,10 +1258,9 @@ __global__ __launch_bounds__(512) void conv1_regw_kernel(const float *__restrict
 #if defined(NQA_R_NO_P1)  // timing-only ablations (tools/gpu_fused_bench.py; results are wrong on purpose)
     conv1_2_tile(it);
     (void)next;
-    raw_commit(it & 1, true);
 #elif defined(NQA_R_NO_P2)
     if (next) conv1_1_halo(it + 1);
-    raw_commit(it & 1, false);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (no stores in this ablation: the counted wait below would not hold)
 #else
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {  // (a loop, so that each phase's code exists once)
@@ -1274,22 +1273,21 @@ __global__ __launch_bounds__(512) void conv1_regw_kernel(const float *__restrict
         conv1_2_tile(it);
         NQA_STAMP(h1);
         NQA_STAMP_ADD(1, h0, h1);
-      } else {
-        if (next) {
-          __builtin_amdgcn_s_setprio(2);
-          conv1_1_halo(it + 1);
-        }
+      } else if (next) {
+        __builtin_amdgcn_s_setprio(2);
+        conv1_1_halo(it + 1);
         NQA_STAMP(h1);
         NQA_STAMP_ADD(2, h0, h1);
-        // tile it+2's patch (patch it&1 was last read by conv1_1 of tile `it`, during tile it-1), committed right behind
-        // this wave's conv1_1 phase: the pixels were requested a phase ago, and the wave's youngest stores are a phase
-        // old too (waves 0-3: this tile's conv1_2; waves 4-7: the previous tile's), so the wait in front of it is short
-        raw_commit(it & 1, wave < 4);
-        NQA_STAMP(h2);
-        NQA_STAMP_ADD(3, h1, h2);
       }
     }
 #endif
+    // tile it+2's patch (patch it&1 was last read by conv1_1 of tile `it`, during tile it-1).  The pixels were requested
+    // a whole tile ago; every wave has issued exactly its 8 stores since (in either phase order), so vmcnt(8) retires
+    // the pixels without waiting for a single store
+    NQA_STAMP(s3);
+    raw_commit(it & 1, true);
+    NQA_STAMP(s4);
+    NQA_STAMP_ADD(3, s3, s4);
   }
 #ifdef NQA_STAMPS
   if (lane == 0) {
@@ -1563,14 +1561,12 @@ __global__ __launch_bounds__(512) void conv1_regw_split_kernel(const float *__re
       if ((half == 0) == (wave < 4)) {
         __builtin_amdgcn_s_setprio(0);
         conv1_2_tile(it);
-      } else {
-        if (next) {
-          __builtin_amdgcn_s_setprio(2);
-          conv1_1_halo(it + 1);
-        }
-        raw_commit(it & 1, wave < 4);  // tile it+2's patch, right behind this wave's conv1_1 phase (see conv1_regw_kernel)
+      } else if (next) {
+        __builtin_amdgcn_s_setprio(2);
+        conv1_1_halo(it + 1);
       }
     }
+    raw_commit(it & 1, true);  // tile it+2's patch; 4 stores younger than its pixels in either phase order (see conv1_regw_kernel)
   }
 #endif
 }
