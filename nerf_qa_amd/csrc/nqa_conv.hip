@@ -499,10 +499,25 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void conv3x3_igemm_kernel(
   // one lane's piece: 4 consecutive channels (first = cl, block-local) of the pixel staged in `row`
   // f32s: the weights were packed times a power of two (nqa_pack_vgg_weights); 1/scale sits behind the bias
   const float winv = (P::SPLIT || NTERM == 2) ? bias[Cout] : 1.f;
-  auto stage_piece = [&](int row, int cl, float a0, float a1, float a2, float a3) {
+  // The wave's bias vectors are fetched HERE, all at once, and land under the barrier below.  Fetched inside
+  // stage_piece they came one at a time, each waited for (global_load -> s_waitcnt vmcnt(0) -> ten VALU -> the next):
+  // sixteen exposed cache round trips per tile on the one-block-per-CU tiles, where nothing else runs beside an epilogue.
+  constexpr int NBQ = M16 ? 2 * WN_T : 4 * WN_T;
+  f32x4 bq[NBQ];
+#pragma unroll
+  for (int q = 0; q < NBQ; ++q) {
+    const int cl = M16 ? wn * WN_T * 32 + q * 16 + 4 * c4 : (wn * WN_T + (q >> 2)) * 32 + 8 * (q & 3) + 4 * h;
+    bq[q] = *reinterpret_cast<const f32x4 *>(bias + ct * G::BN + cl);
+  }
+  auto stage_piece = [&](int row, int cl, const f32x4 &b4_pre, float a0, float a1, float a2, float a3) {
     char *const rbase = smem + row * RB;
     const int sw = row & SWZ;
+#ifdef NQA_EPI_BIAS_INLINE  // A/B build: the round-2 form (one bias load per piece, waited for in place)
     const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bias + ct * G::BN + cl);
+    (void)b4_pre;
+#else
+    const f32x4 &b4 = b4_pre;
+#endif
     if constexpr (P::SPLIT || NTERM == 2) {  // exact: winv is a power of two
       a0 *= winv;
       a1 *= winv;
@@ -541,15 +556,15 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void conv3x3_igemm_kernel(
 #pragma unroll
         for (int i = 0; i < 2 * WN_T; ++i) {
           const f32x4 &c = acc16[i][2 * j + jj];
-          stage_piece(wm * 32 + jj * 16 + l15, wn * WN_T * 32 + i * 16 + 4 * c4, c[0], c[1], c[2], c[3]);
+          stage_piece(wm * 32 + jj * 16 + l15, wn * WN_T * 32 + i * 16 + 4 * c4, bq[i], c[0], c[1], c[2], c[3]);
         }
     } else {
 #pragma unroll
       for (int i = 0; i < WN_T; ++i)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-          stage_piece(wm * 32 + l31, (wn * WN_T + i) * 32 + 8 * g + 4 * h, acc[i][j][4 * g], acc[i][j][4 * g + 1],
-                      acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+          stage_piece(wm * 32 + l31, (wn * WN_T + i) * 32 + 8 * g + 4 * h, bq[M16 ? 0 : 4 * i + g], acc[i][j][4 * g],
+                      acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
     }
     __syncthreads();
 #pragma unroll 2
