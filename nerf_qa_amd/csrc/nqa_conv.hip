@@ -894,7 +894,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_regw128_kernel(const typename 
   for (int it = 0; it < my_tiles; ++it) {
     int n, x0, y0, ct;
     tile_coords(it, n, x0, y0, ct);
-    if (ct != cur_ct) load_weights(ct);  // (block-uniform; compiler-tracked loads)
+    if (ct != cur_ct) {  // (block-uniform; compiler-tracked loads)
+      load_weights(ct);
+      // Retire them HERE, with a wait the compiler can see (the builtin, not inline asm): left pending, the fragments
+      // are "values loaded outside a store-only loop that uses them" at the pass loop below, and for that shape the
+      // waitcnt pass drains vmcnt(0) in front of the loop -- on EVERY tile, right behind issue_halo(it + 1), i.e. the
+      // next tile's halo was waited for before this tile's first MFMA (found in the ISA, round 3)
+#ifndef NQA_NO_VISIBLE_WAIT  // (A/B build switch)
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched
+#endif
+    }
     // halo `it` has landed: the only younger operations are the previous tile's stores
     if (it == 0)
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
