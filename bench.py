@@ -13,17 +13,21 @@ The line's `value` is the headline workload, BASELINE.json configs[2]: B=8 pairs
 step through DISTS.forward in its shipped precision mode -- "auto": the fastest of f16 / f16w / f32m4 / f32m / f32m2 /
 f32s that the module's one-time calibration of its VGG weights admits (384 synthetic pairs through every rung; a mode is
 admitted when its deviation from f32s stays well inside the 1e-4 bar AND looks like noise rather than outliers,
-DISTS_pt.py header).  For the stand-in weights used here that is f16w (f16 activations x two-term weights: two MFMAs per
-product) -- plain f16 is refused (6.5e-5 on the calibration set) -- and the line says so in `dtype`, `config.precision`
-and `config.auto_calibration`.  Frames are resident in HBM.  Frames
+DISTS_pt.py header), per frame-size class.  For the stand-in weights used here (`synth:1234`, gain 1.0) and 1080p frames
+that is plain f16 (the smallest class, 128x128 .. 224x224, gets f16w instead); weights with ImageNet-like activation growth
+(gain 1.3) calibrate to f32m at 1080p and the stress set (gain 1.6) to f32s -- the line says what ran in `dtype`,
+`config.precision`, `config.auto_calibration`, and carries the other two defaults as companions.  Frames are resident in HBM.  Frames
 shard across ranks with no data-path collective; the only exchange is ONE all-gather of the per-frame scores
 after the last step (inside the timed region) -- weak scaling, K steps of 8 pairs on every GPU.
 
 At N=1 the same JSON line also carries, under "workloads", the rest of the metric ("1080p & 256^2", DISTS
 and A-DISTS) measured the same way in the same process: 1080p in f16 (the opt-in fast mode: one MFMA per product; NOT
-what any of the pinned weight sets calibrates to), in f32m / f32m2 and in f32s (float32 activations, split-f16 products: the
-reference's own precision class, what `auto` runs when nothing faster is admitted), 256x256 B=32 (configs[1]) in f16 /
-f32m / f32s, and A-DISTS at 1080p B=8 (configs[4], f32s).  Every entry has its own
+what `auto` admits for every weight set), in f32m / f32m2 and in f32s (float32 activations, split-f16 products: the
+reference's own precision class, what `auto` runs when nothing faster is admitted), the shipped default ON THE OTHER TWO
+PINNED WEIGHT SETS (`1080p/auto@gain1.3`: the ImageNet-like activation magnitude, `1080p/auto@gain1.6`: the stress set --
+whatever rung each calibrates to, with its calibration report), exact `f32` (the only mode with the reference's 24-bit
+products; peak 157.3 TF), 256x256 B=32 (configs[1]) in f16 / f32m / f32s, and A-DISTS at 1080p B=8 (configs[4], f32s).
+`config.default_by_weight_set` puts the three defaults side by side.  Every entry has its own
 `roofline` (the MFMA conv stack: algorithmic FLOPs of layers 1..12 / the HIP-event time of those launches, measured
 inside the timed region on the launch stream; `peak` is always the guide's dense 2.5 PFLOP/s f16 figure, and for
 f32m / f32s both the algorithmic and the issued-MFMA fraction are given) and `roofline_hbm` (the HBM-bound L2-pool +
@@ -67,7 +71,10 @@ WORKLOADS = {
                           "seed = frame index, sharded over the ranks", B=8, H=1080, W=1920, metric="DISTS"),
 }
 # what the N=1 line measures beside the headline (workload key, precision)
-COMPANIONS = (("1080p", "f16"), ("1080p", "f16w"), ("1080p", "f32m"), ("1080p", "f32m2"), ("1080p", "f32s"),
+# what the N=1 line measures beside the headline: (workload key, precision[, VGG weight spec]); precision None = the
+# shipped default (`auto`) calibrated on that weight set
+COMPANIONS = (("1080p", None, "synth:1234:1.3"), ("1080p", None, "synth:1234:1.6"),
+              ("1080p", "f16"), ("1080p", "f16w"), ("1080p", "f32m"), ("1080p", "f32m2"), ("1080p", "f32s"), ("1080p", "f32"),
               ("256", "f16"), ("256", "f16w"), ("256", "f32m"), ("256", "f32s"),
               ("adists1080p", "f32s"))  # (the one the headline itself ran in is skipped)
 PEAK_F16_TFLOPS = 2500.0  # dense f16/bf16 MFMA, MI355X_MICROARCH.md
@@ -236,17 +243,20 @@ def cpu_baseline(h, w, budget_s=24.0, adists=False):
                                       f"median of {len(times)} after 1 warm-up"}
 
 
-def make_model(metric, precision, dev, h, w):
+def make_model(metric, precision, dev, h, w, vgg=VGG):
     """-> (callable(ref, render) -> (B,) scores, the precision mode it runs this frame size in, weight source)."""
     if metric == "A-DISTS":
-        net = ADISTS(precision=precision, vgg16_path=VGG).to(dev).eval()
+        net = ADISTS(precision=precision, vgg16_path=vgg).to(dev).eval()
         return (lambda a, b: net(a, b, as_loss=False)), net.precision_for(h, w), net.vgg_source  # x = reference frame
-    net = DISTS(precision=precision, vgg16_path=VGG).to(dev).eval()
-    # "auto" (the default) calibrates every rung against f32s with these weights, once per frame-size class; under a
-    # process group all ranks then run the most accurate rung any of them chose (one mode per video whatever N)
+    net = DISTS(precision=precision, vgg16_path=vgg).to(dev).eval()
+    # "auto" (the default) takes its verdict from the calibration file when these weights were calibrated on this device
+    # model and library build before, else measures every rung against f32s once; under a process group rank 0 does
+    # that and broadcasts the report (one mode per video whatever N, one calibration per job)
     prec = sharding.agree_precision(net, h, w, dev)
     if net.precision == "auto":
-        AUTO_REPORT.update({k: (round(v, 9) if isinstance(v, float) else v) for k, v in net.calibrate(dev, h, w).items()})
+        rep = getattr(net, "_agreed_report", None) or net.calibrate(dev, h, w)
+        AUTO_REPORT.clear()
+        AUTO_REPORT.update({k: (round(v, 9) if isinstance(v, float) else v) for k, v in rep.items()})
     return net, prec, net.vgg_source
 
 
@@ -257,11 +267,11 @@ def synth_frames(b, h, w, dev, seed):
     return x, y
 
 
-def run_workload(key, precision, steps, warmup, dev, world, rank, batch=0):
+def run_workload(key, precision, steps, warmup, dev, world, rank, batch=0, vgg=VGG):
     """K timed steps of one workload on this rank; returns (dt max-over-ranks, scores, ktimes, prec, B, H, W, src)."""
     wl = WORKLOADS[key]
     B, H, W = batch or wl["B"], wl["H"], wl["W"]
-    model, prec, src = make_model(wl["metric"], precision, dev, H, W)
+    model, prec, src = make_model(wl["metric"], precision, dev, H, W, vgg)
     # synthetic frames generated on the device (no host I/O anywhere); each rank seeds with its rank so shards differ
     x, y = synth_frames(B, H, W, dev, 1000 + rank)
 
@@ -338,14 +348,35 @@ def self_launch(n, argv):
     env.setdefault("OMP_NUM_THREADS", "4")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
-    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True)
-    for line in proc.stdout:
-        if line.startswith('{"metric"'):
-            sys.stdout.write(line)
-            sys.stdout.flush()
-        else:
-            sys.stderr.write(line)
-    return proc.wait()
+    # a wall-clock limit on the whole job (NQA_BENCH_LAUNCH_TIMEOUT seconds, default 30 min): a hung rank must not block
+    # the launcher for ever -- the child's process GROUP is terminated and the launcher exits non-zero
+    limit = float(os.environ.get("NQA_BENCH_LAUNCH_TIMEOUT", "1800"))
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True, start_new_session=True)
+    import signal
+    import threading
+
+    def expire():
+        sys.stderr.write(f"bench.py: the {n}-rank job exceeded {limit:.0f} s; terminating its process group\n")
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(proc.pid, sig)  # (start_new_session: the child leads its own group -- nothing else is in it)
+            except ProcessLookupError:
+                return
+            time.sleep(5)
+    timer = threading.Timer(limit, expire)
+    timer.daemon = True
+    timer.start()
+    try:
+        for line in proc.stdout:
+            if line.startswith('{"metric"'):
+                sys.stdout.write(line)
+                sys.stdout.flush()
+            else:
+                sys.stderr.write(line)
+        rc = proc.wait()
+    finally:
+        timer.cancel()
+    return rc if rc >= 0 else 124  # (killed by the limit: the conventional timeout code)
 
 
 def run_stub(steps, warmup, world, rank):
@@ -488,7 +519,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": wl["name"], "pairs_per_gpu_per_step": B, "height": H, "width": W,
                        "vgg_weights": src, "sharding": f"frames/{world} ranks, one all-gather of scores",
-                       "precision": (args.precision or "auto (shipped default)") + " -> " + prec,
+                       "precision": (args.precision or "auto (shipped default)") + " -> " + prec
+                                    + ("" if args.precision else " on the gain-1.0 stand-in weights; the same default runs f32m on the "
+                                       "ImageNet-magnitude set (gain 1.3) and f32s on the stress set (gain 1.6): see "
+                                       "config.default_by_weight_set and workloads 1080p/auto@gain1.3, @gain1.6"),
                        "auto_calibration": dict(AUTO_REPORT) if not args.precision and wl["metric"] == "DISTS" else None,
                        "timing": "hipEvent pairs around every kernel launch are recorded inside the timed region"},
             "per_rank_pairs_per_s": [round(B * args.steps / t, 2) for t in per],
@@ -498,18 +532,33 @@ def main():
         }
     if world == 1 and not args.only and args.workload == "1080p" and not args.batch:
         comp = {}
-        for key, cprec in COMPANIONS:
-            if (key, cprec) == (args.workload, prec):
+        defaults = {"gain 1.0 (synth:1234, the headline)": {"mode": prec, "pairs_per_s": out["value"],
+                                                            "conv_frac_of_2.5PF": roof["frac"]}}
+        for entry in COMPANIONS:
+            key, cprec = entry[0], entry[1]
+            vgg = entry[2] if len(entry) > 2 else VGG
+            if (key, cprec, vgg) == (args.workload, prec, VGG):
                 continue  # that is the headline
-            cdt, ckt, cp, cb, ch, cw, _ = run_workload(key, cprec, args.steps, args.warmup, dev, 1, 0)
+            cdt, ckt, cp, cb, ch, cw, csrc = run_workload(key, cprec, args.steps, args.warmup, dev, 1, 0, vgg=vgg)
             croof, chbm, ckms = rooflines(ckt, ch, cw, cb, cp, traffic_for(traffic, f"{key}/{cp}"))
-            comp[f"{key}/{cp}"] = {"workload": WORKLOADS[key]["name"], "metric": WORKLOADS[key]["metric"] + " frame-pairs/s",
-                                   "value": round(cb * args.steps / cdt, 2), "unit": "frame-pairs/s",
-                                   "ms_per_step": round(cdt / args.steps * 1e3, 4), "dtype": cp,
-                                   "pairs_per_gpu_per_step": cb, "roofline": croof, "kernel_ms_per_step": ckms,
-                                   "roofline_hbm": chbm}
+            name = f"{key}/{cp}" if cprec is not None else f"{key}/auto@gain{vgg.rsplit(':', 1)[1]}"
+            comp[name] = {"workload": WORKLOADS[key]["name"], "metric": WORKLOADS[key]["metric"] + " frame-pairs/s",
+                          "value": round(cb * args.steps / cdt, 2), "unit": "frame-pairs/s",
+                          "ms_per_step": round(cdt / args.steps * 1e3, 4), "dtype": cp,
+                          "pairs_per_gpu_per_step": cb, "roofline": croof, "kernel_ms_per_step": ckms,
+                          "roofline_hbm": chbm}
+            if cprec is None:  # the shipped default on another pinned weight set: say what it calibrated to, and why
+                comp[name]["vgg_weights"] = csrc
+                comp[name]["precision"] = "auto (shipped default) -> " + cp
+                comp[name]["auto_calibration"] = dict(AUTO_REPORT)
+                defaults[f"gain {vgg.rsplit(':', 1)[1]} ({vgg})"] = {"mode": cp, "pairs_per_s": comp[name]["value"],
+                                                                    "conv_frac_of_2.5PF": croof["frac"],
+                                                                    "frac_of_issued_mfma": croof.get("frac_of_issued_mfma")}
             torch.cuda.empty_cache()
         out["workloads"] = comp
+        # the three pinned weight sets side by side: what a user's checkpoint gets depends on how it grows activations
+        # (gain 1.3 is the ImageNet magnitude); the headline `value` is the first of these
+        out["config"]["default_by_weight_set"] = defaults
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(H, W, adists=wl["metric"] == "A-DISTS")

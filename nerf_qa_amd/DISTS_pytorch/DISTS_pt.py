@@ -76,7 +76,6 @@ AUTO_CLASSES = (
     (640 * 640, ((192, 640, 640, 20265), (64, 600, 1000, 20266))),
     (900 * 1000, ((224, 720, 1280, 20267), (32, 1080, 1920, 20268))),
 )
-AUTO_CAL_SETS = AUTO_CLASSES[0][1]
 
 
 def walk_ladder(figures: dict, budget: float = AUTO_F16_BUDGET, rms_budget: float = AUTO_F16_RMS,
@@ -101,7 +100,8 @@ def size_class(h: int, w: int) -> int:
         if h * w >= first:
             k = i
     return k
-AUTO_CAL_PAIRS, AUTO_CAL_SIZE = 128, 128
+
+
 # the ladder `auto` climbs, fastest first (two-term stages: f16w all five, f32m4 four, f32m three, f32m2 two)
 LADDER = ("f16", "f16w", "f32m4", "f32m", "f32m2", "f32s")
 
@@ -116,28 +116,95 @@ def admitted(mx: float, rms: float, budget: float = AUTO_F16_BUDGET, rms_budget:
     return rms <= rms_budget and (mx <= safe_max or (mx <= budget and tail <= tail_budget))
 
 
-def calibration_pairs(dev, n=AUTO_CAL_PAIRS, size=AUTO_CAL_SIZE, seed=20261, width=None):
-    """An (x, y) batch `auto` calibrates on: smooth-plus-noise frames (so that blur changes structure) and the four
-    distortion families of SURVEY 8d, generated on the device from a fixed seed (size x width pixels, square by default)."""
+def calibration_pairs(dev, n=128, size=128, seed=20261, width=None):
+    """An (x, y) batch `auto` calibrates on, generated on the device from a fixed seed (size x width pixels, square by
+    default).  Five pairs of every eight are smooth-plus-noise frames (so that blur changes structure) under the four
+    distortion families of SURVEY 8d; three of every eight are NeRF-render-like (round 4): a textured object on an exactly
+    constant white or black background covering 40-70 % of the frame, and a smooth frame with a few small floaters --
+    the content that produces exactly dead VGG channels, where the faster rungs' outliers live."""
     g = torch.Generator(device=dev).manual_seed(seed)
     h, w = size, (width or size)
-    low = torch.nn.functional.interpolate(torch.rand(n, 3, h // 16, w // 16, device=dev, generator=g),
-                                          size=(h, w), mode="bilinear", align_corners=False)
+    F = torch.nn.functional
+    low = F.interpolate(torch.rand(n, 3, max(h // 16, 2), max(w // 16, 2), device=dev, generator=g),
+                        size=(h, w), mode="bilinear", align_corners=False)
     x = 0.6 * torch.rand(n, 3, h, w, device=dev, generator=g) + 0.4 * low
     y = torch.empty_like(x)
     noise = torch.randn(n, 3, h, w, device=dev, generator=g)
     other = torch.rand(n, 3, h, w, device=dev, generator=g)
+    # object masks / floaters: soft discs from a coarse random field (two thresholds give two slightly different silhouettes)
+    field = F.interpolate(torch.rand(n, 1, 5, 5, device=dev, generator=g), size=(h, w), mode="bicubic", align_corners=False)
+    par = torch.rand(n, 8, device=dev, generator=g)
     for i in range(n):
-        k = i % 4
-        if k == 0:
-            y[i] = (x[i] + 0.02 * noise[i]).clamp(0, 1)
+        k = i % 8
+        if k in (0, 4):
+            y[i] = (x[i] + (0.02 if k == 0 else 0.10) * noise[i]).clamp(0, 1)
         elif k == 1:
             y[i] = (x[i] + 0.10 * noise[i]).clamp(0, 1)
         elif k == 2:
-            y[i] = torch.nn.functional.avg_pool2d(x[i:i + 1], 5, 1, 2, count_include_pad=False)[0]
-        else:
+            y[i] = F.avg_pool2d(x[i:i + 1], 5, 1, 2, count_include_pad=False)[0]
+        elif k == 3:
             y[i] = other[i]
+        elif k in (5, 6):  # constant background (white / black), object slightly blurred + noisy, silhouette a little off
+            bg = 1.0 if k == 5 else 0.0
+            thr = 0.5 + 0.15 * float(par[i, 0])  # roughly 40-70 % background
+            m = ((field[i] - thr) * 40.0).clamp(0, 1)
+            m2 = ((field[i] - thr - 0.01) * 40.0).clamp(0, 1)
+            obj = 0.5 * x[i] + 0.5 * F.avg_pool2d(x[i:i + 1], 5, 1, 2, count_include_pad=False)[0] + 0.03 * noise[i]
+            xi = m * x[i] + (1 - m) * bg
+            y[i] = (m2 * obj + (1 - m2) * bg).clamp(0, 1)
+            x[i] = xi
+        else:  # k == 7: a smooth frame (no per-pixel noise) and a render with small floaters
+            xi = low[i] * 0.5 + 0.25
+            blob = ((field[i] - 0.86) * 60.0).clamp(0, 1)  # a few per cent of the frame
+            y[i] = ((1 - blob) * F.avg_pool2d(xi[None], 5, 1, 2, count_include_pad=False)[0] + blob * par[i, 1:4].view(3, 1, 1)).clamp(0, 1)
+            x[i] = xi
     return x, y
+
+
+def cal_cache_path():
+    """The calibration file: $NQA_CAL_CACHE (a path; "off" / "0" / "" disables it), default
+    ~/.cache/nerf_qa_amd/dists_auto_calibration.json.  One JSON object {key: report}; a key names the VGG weights (by
+    content), the device model, the library's source hash, the size class with its calibration sets and the thresholds,
+    so a stale entry can never be picked up -- it is simply never looked for again."""
+    v = os.environ.get("NQA_CAL_CACHE")
+    if v is not None:
+        return None if v.lower() in ("", "0", "off", "none") else v
+    return os.path.join(os.path.expanduser("~"), ".cache", "nerf_qa_amd", "dists_auto_calibration.json")
+
+
+def cal_cache_get(key: str):
+    path = cal_cache_path()
+    if not path:
+        return None
+    try:
+        import json
+        with open(path) as f:
+            rep = json.load(f).get(key)
+        return dict(rep) if isinstance(rep, dict) and rep.get("choice") in LADDER else None
+    except (OSError, ValueError):
+        return None
+
+
+def cal_cache_put(key: str, report: dict) -> None:
+    """Best effort (a read-only home directory must not break scoring): read-modify-write through a temporary file."""
+    path = cal_cache_path()
+    if not path:
+        return
+    try:
+        import json
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        try:
+            with open(path) as f:
+                table = json.load(f)
+        except (OSError, ValueError):
+            table = {}
+        table[key] = {k: v for k, v in report.items() if k != "source"}
+        tmp = f"{path}.{os.getpid()}.tmp"
+        with open(tmp, "w") as f:
+            json.dump(table, f)
+        os.replace(tmp, path)
+    except OSError:
+        pass
 
 
 class L2pooling(nn.Module):
@@ -211,6 +278,8 @@ class DISTS(torch.nn.Module):
         self._packed = {}
         self._ws = ops.Workspace()
         self._auto = None  # (weights key, {size class: report}) once calibrated
+        self._deltas = {}  # {size class: {mode: (dS1, dS2)}} similarity deviations, kept for _live_choice only
+        self._agreed = {}  # {size class: (weights key, mode)} set by sharding.agree_precision under a process group
 
     # ---- plumbing -----------------------------------------------------------------
     def _conv_modules(self):
@@ -220,6 +289,11 @@ class DISTS(torch.nn.Module):
     def _weights_key(self, dev):
         return (str(dev),) + tuple((m.weight._version, m.weight.data_ptr()) for m in self._conv_modules())
 
+    # ---- `auto`: where the verdict comes from ----------------------------------------------
+    # memory (self._auto, per weight set / device / size class)  ->  the calibration file (cal_cache_path(): written by
+    # whichever process measured first; keyed by the VGG weights' content, the device model, the HIP sources' hash and
+    # the thresholds)  ->  a measurement (calibrate()).  Under a process group sharding.agree_precision() has rank 0 do
+    # that and broadcasts the report; the agreed choice lives in self._agreed, apart from the calibration cache.
     def precision_for(self, h: int, w: int, device=None) -> str:
         """The precision mode a frame size runs in.  "auto": f32s below AUTO_MIN_PIXELS; above, what the one-time
         calibration of these weights on `device` (default: where alpha lives) allows -- see the module header."""
@@ -227,15 +301,54 @@ class DISTS(torch.nn.Module):
             return self.precision
         if h * w < AUTO_MIN_PIXELS:
             return "f32s"
-        return self.calibrate(device if device is not None else self.alpha.device, h, w)["choice"]
+        device = torch.device(device if device is not None else self.alpha.device)
+        cls = max(size_class(h, w), 0)
+        hit = self._agreed.get(cls)
+        if hit is not None and hit[0] == self._weights_key(device):
+            return hit[1]
+        report = self.calibrate(device, h, w)
+        live = self._live_weights(device)
+        if live is not None:  # alpha / beta are not the published ones: the verdict for THESE weights (see _live_choice)
+            return self._live_choice(device, cls, h, w, live)
+        return report["choice"]
+
+    def calibrate_all(self, device) -> dict:
+        """Calibrate every frame-size class now ({class index: report}): 0.15 + 0.4 + 1.9 + 4.3 s on an MI355X when
+        nothing is cached, nothing when the calibration file already holds these weights on this device model and
+        library build.  Call it once at start-up to keep the measurement out of the first forward() of each class."""
+        return {cls: self.calibrate(device, *AUTO_CLASSES[cls][1][0][1:3]) for cls in range(len(AUTO_CLASSES))}
+
+    def _vgg_digest(self) -> str:
+        """sha256 over the thirteen conv layers' weights and biases (content, not identity): the calibration file's key."""
+        key = tuple((m.weight._version, m.weight.data_ptr()) for m in self._conv_modules())
+        hit = self.__dict__.get("_digest")
+        if hit is None or hit[0] != key:
+            import hashlib
+            hh = hashlib.sha256()
+            for m in self._conv_modules():
+                hh.update(m.weight.detach().cpu().contiguous().numpy().tobytes())
+                hh.update(m.bias.detach().cpu().contiguous().numpy().tobytes())
+            hit = self.__dict__["_digest"] = (key, hh.hexdigest()[:32])
+        return hit[1]
+
+    def _cal_file_key(self, device, cls, thresholds) -> str:
+        try:
+            from .. import build as nqa_build
+            lib = os.environ.get("NQA_LIB") or nqa_build.source_hash()
+        except OSError:  # (sources not shipped beside the library: fall back to the library file itself)
+            lib = "lib:%d" % os.path.getsize(os.path.join(os.path.dirname(_DATA), "..", "libnqa_hip.so"))
+        devname = torch.cuda.get_device_name(device) if device.type == "cuda" else str(device)
+        return "|".join([self._vgg_digest(), devname, str(lib), "class%d" % cls, repr(AUTO_CLASSES[cls]),
+                         repr(LADDER), repr(thresholds)])
 
     @torch.no_grad()
-    def calibrate(self, device, h: int = 128, w: int = 128, force: bool = False) -> dict:
+    def calibrate(self, device, h: int = 128, w: int = 128, force: bool = False, keep_deltas: bool = False) -> dict:
         """Measure every faster rung of LADDER against f32s with this module's VGG weights on `device`, for the
-        frame-size class of h x w (once per weight set, device and class), and decide what `auto` runs frames of that
-        class in: the fastest mode whose deviation from f32s stays inside the budgets (module header).  Returns the
-        report {"choice", "<mode>": {max_abs_diff, rms_diff, tail, ok} for every rung, "budget", "rms_budget",
-        "tail_budget", "safe_max", "pairs", "sizes", "size_class"}."""
+        frame-size class of h x w (once per weight set, device model, library build and class: the report is kept in
+        memory AND in the calibration file, cal_cache_path()), and decide what `auto` runs frames of that class in: the
+        fastest mode whose deviation from f32s stays inside the budgets (module header).  Returns the report {"choice",
+        "<mode>": {max_abs_diff, rms_diff, tail, ok} for every rung, "budget", "rms_budget", "tail_budget", "safe_max",
+        "pairs", "sizes", "size_class", "source": "measured" | "file"}."""
         device = torch.device(device)
         if device.type != "cuda":
             raise NqaError("precision='auto' calibrates on the GPU: move the module to cuda first "
@@ -244,36 +357,49 @@ class DISTS(torch.nn.Module):
         key = self._weights_key(device)
         if self._auto is None or self._auto[0] != key:
             self._auto = (key, {})
-        if not force and cls in self._auto[1]:
+            self._deltas = {}
+        if not force and cls in self._auto[1] and not (keep_deltas and cls not in self._deltas):
             return self._auto[1][cls]
         cal_sets = AUTO_CLASSES[cls][1]
         budget = float(os.environ.get("NQA_AUTO_F16_BUDGET", AUTO_F16_BUDGET))
         rms_budget = float(os.environ.get("NQA_AUTO_F16_RMS", AUTO_F16_RMS))
         tail_budget = float(os.environ.get("NQA_AUTO_TAIL", AUTO_TAIL))
         safe_max = float(os.environ.get("NQA_AUTO_SAFE_MAX", AUTO_SAFE_MAX))
+        thresholds = (budget, rms_budget, tail_budget, safe_max)
+        fkey = self._cal_file_key(device, cls, thresholds)
+        if not force and not keep_deltas:
+            report = cal_cache_get(fkey)
+            if report is not None:
+                report["source"] = "file: " + str(cal_cache_path())
+                self._auto[1][cls] = report
+                return report
         ws = ops.Workspace()  # private scratch (a few GB for 256 pairs of 128x128 in f32s), released again below
-        # weighted with the PUBLISHED alpha/beta: the calibration then depends on the VGG weights only (not on where
-        # fine-tuning has moved alpha/beta, nor on a variant's logit / clamped parametrisation of them)
+        # weighted with the PUBLISHED alpha/beta: the verdict then depends on the VGG weights only; a module whose
+        # alpha/beta have been trained away from them gets its own verdict from the kept similarity deltas (_live_choice)
         ab = np.load(_DATA)
         a, b = torch.from_numpy(ab["alpha"]).to(device), torch.from_numpy(ab["beta"]).to(device)
         modes = LADDER[:-1]
         dev_of = {m: [] for m in modes}
+        deltas = {m: ([], []) for m in modes}
         npairs = 0
         for n, ch, cw, seed in cal_sets:
             bs = max(1, min(n, (64 * 128 * 128) // (ch * cw) * 4))  # batches of a few hundred MB of frames
             for i0 in range(0, n, bs):
                 x, y = calibration_pairs(device, n=min(bs, n - i0), size=ch, seed=seed + 1000 * (i0 // bs), width=cw)
-                score = {}
+                score, sims = {}, {}
                 for prec in modes + ("f32s",):
                     s1, s2 = ops.dists_forward(x, y, self._packed_weights(device, prec), prec, ws)
-                    score[prec] = ops.dists_score(s1, s2, a, b)
+                    score[prec], sims[prec] = ops.dists_score(s1, s2, a, b), (s1, s2)
                 for m in modes:
                     dev_of[m].append((score[m] - score["f32s"]).double())
+                    if keep_deltas:
+                        deltas[m][0].append(sims[m][0] - sims["f32s"][0])
+                        deltas[m][1].append(sims[m][1] - sims["f32s"][1])
                 del x, y
             npairs += n
         report = {"budget": budget, "rms_budget": rms_budget, "tail_budget": tail_budget, "safe_max": safe_max, "pairs": npairs,
                   "size_class": cls, "class_from_pixels": AUTO_CLASSES[cls][0],
-                  "sizes": [f"{n}x {ch}x{cw}" for n, ch, cw, _ in cal_sets]}
+                  "sizes": [f"{n}x {ch}x{cw}" for n, ch, cw, _ in cal_sets], "source": "measured"}
         figures = {}
         for prec in LADDER[:-1]:
             d = torch.cat(dev_of[prec])
@@ -288,7 +414,53 @@ class DISTS(torch.nn.Module):
         report["max_abs_diff"], report["rms_diff"] = report["f16"]["max_abs_diff"], report["f16"]["rms_diff"]
         del ws
         self._auto[1][cls] = report
+        if keep_deltas:  # (pairs, 1475) per rung and similarity: 27 MB per class at 384 pairs
+            self._deltas[cls] = {m: (torch.cat(deltas[m][0]), torch.cat(deltas[m][1])) for m in modes}
+        cal_cache_put(fkey, report)
         return report
+
+    # ---- alpha / beta that are not the published ones (fine-tuning: run_nerf_qa.py:454-462) -----------------------
+    def _score_weights(self):
+        """(alpha / w, beta / w) as this class's forward applies them to S1 / S2, flat float32 (1475,) tensors (the
+        `_original` / `_softmax` variants override this with their own parametrisation)."""
+        a, b = self.alpha.detach().reshape(-1).float(), self.beta.detach().reshape(-1).float()
+        wsum = a.sum() + b.sum()
+        return a / wsum, b / wsum
+
+    def _live_weights(self, device):
+        """None while alpha/beta still score like the published weights; else the (alpha/w, beta/w) in use.  Checked once
+        per change of alpha/beta (their version counters), so an inference module pays for it once."""
+        ver = (self.alpha._version, self.beta._version, self.alpha.data_ptr(), self.beta.data_ptr(), type(self).__name__)
+        hit = self.__dict__.get("_live")
+        if hit is None or hit[0] != ver:
+            a, b = self._score_weights()
+            ab = np.load(_DATA)
+            pa, pb = torch.from_numpy(ab["alpha"]).to(a.device), torch.from_numpy(ab["beta"]).to(a.device)
+            pw = pa.sum() + pb.sum()
+            same = bool(((a - pa / pw).abs().max() <= 1e-7) & ((b - pb / pw).abs().max() <= 1e-7))
+            hit = self.__dict__["_live"] = (ver, None if same else (a.to(device), b.to(device)), {})
+        return hit[1]
+
+    @torch.no_grad()
+    def _live_choice(self, device, cls, h, w, live) -> str:
+        """`auto` for a module whose alpha/beta have moved: the rungs' errors sit in a few nearly dead
+        channels, so weights that lean on those channels can push a rung past 1e-4 that the published weights admit.  The
+        calibration keeps each rung's similarity deviations (dS1, dS2 per pair and channel); the deviation of the SCORE
+        under any alpha/beta is their weighted sum, so the ladder is walked again with the weights in use -- two small
+        matrix-vector products per rung whenever alpha/beta change, no new measurement."""
+        memo = self.__dict__["_live"][2]
+        if cls in memo:
+            return memo[cls]
+        rep = self.calibrate(device, h, w, keep_deltas=True)
+        a, b = live
+        figures = {}
+        for m, (d1, d2) in self._deltas[cls].items():
+            d = -(d1.double() @ a.double() + d2.double() @ b.double())
+            ok = bool(torch.isfinite(d).all())
+            figures[m] = (float(d.abs().max()), float(d.pow(2).mean().sqrt())) if ok else (float("inf"), float("inf"))
+        choice, _ = walk_ladder(figures, rep["budget"], rep["rms_budget"], rep["tail_budget"], rep["safe_max"])
+        memo[cls] = choice
+        return choice
 
     def _packed_weights(self, dev, prec=None):
         if prec is None:
@@ -308,6 +480,10 @@ class DISTS(torch.nn.Module):
         d.pop("_packed", None)
         d.pop("_ws", None)  # (__setstate__ rebuilds both)
         d["_auto"] = None
+        for k in ("_deltas", "_agreed"):
+            d[k] = {}
+        for k in ("_bwd_blobs", "_live", "_digest"):  # device tensors / per-process memos (autograd.py's blobs: 60 MB of
+            d.pop(k, None)                            # CUDA tensors that a CPU-only torch.load could not even open)
         return d
 
     def __setstate__(self, state):
@@ -318,7 +494,7 @@ class DISTS(torch.nn.Module):
         d = self.__dict__
         d.setdefault("precision", os.environ.get("NQA_PRECISION", DEFAULT_PRECISION))
         d.setdefault("vgg_source", "unpickled module (Conv2d weights of stage1..5)")
-        d["_packed"], d["_ws"], d["_auto"] = {}, ops.Workspace(), None
+        d["_packed"], d["_ws"], d["_auto"], d["_deltas"], d["_agreed"] = {}, ops.Workspace(), None, {}, {}
 
     def _similarities(self, x, y, require_grad=False):
         if x.shape != y.shape:

@@ -51,6 +51,14 @@ class DISTS(_BaseDISTS):
         self.alpha.data = alpha / weight_sum
         self.beta.data = beta / weight_sum
 
+    def _score_weights(self):  # (what `auto` re-walks its ladder with once alpha/beta have moved; DISTS_pt._live_choice)
+        flags = str(config().dists_weight_norm).split("+")
+        a, b = self.alpha.detach().reshape(-1).float(), self.beta.detach().reshape(-1).float()
+        if "relu" in flags:
+            a, b = torch.relu(a), torch.relu(b)
+        wsum = a.sum() + b.sum()
+        return a / wsum, b / wsum
+
     def forward(self, x, y, require_grad=False, batch_average=False):
         s1, s2 = self._similarities(x, y, require_grad)
         flags = str(config().dists_weight_norm).split("+")

@@ -35,6 +35,10 @@ class DISTS(_BaseDISTS):
                 setattr(self, name, fn(getattr(self, name)))
         return self
 
+    def _score_weights(self):  # (DISTS_pt._live_choice)
+        w = torch.softmax(torch.cat([self.alpha.detach(), self.beta.detach()], dim=1).float(), dim=1).reshape(-1)
+        return w[:self.alpha.numel()], w[self.alpha.numel():]
+
     def forward(self, x, y, require_grad=False, batch_average=False, warp=None, certainty=None):
         s1, s2 = self._similarities(x, y, require_grad)
         w = torch.softmax(torch.cat([self.alpha, self.beta], dim=1), dim=1)

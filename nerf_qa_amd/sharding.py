@@ -53,21 +53,34 @@ def score_frames_sharded(score_batch: Callable[[int, int], torch.Tensor], n_fram
 
 
 def agree_precision(model, h: int, w: int, device, group=None) -> str:
-    """DISTS `auto` under a process group: every rank calibrates on its own GPU (the measurement is deterministic, but
-    two GPUs may land on different sides of a threshold), then ALL ranks adopt the most accurate rung any rank chose, so
-    the frames of one video are scored in one mode whatever the world size.  Returns the mode frames of h x w run in;
-    a module with a named precision, or no process group, is returned as it is."""
-    prec = model.precision_for(h, w, device)
+    """DISTS `auto` under a process group: ONE verdict per job.  Rank 0 resolves the calibration report of the frame's
+    size class (memory, the calibration file, or -- once per weight set, device model and library build -- a measurement
+    on its GPU) and broadcasts it; the other ranks adopt it without launching anything, so an 8-rank job pays for one
+    calibration, not eight, and the frames of one video are scored in one mode whatever the world size or which rank an
+    empty shard lands on.  (Until round 3 every rank measured and the most accurate choice won; the measurement is
+    deterministic for one device model and build, so rank 0's is as good as any.)  The agreed mode is kept on the module
+    apart from the calibration cache (`model._agreed`), keyed by the weights it was agreed for.  Returns the mode frames
+    of h x w run in; a module with a named precision, or no process group, is returned as it is."""
     if getattr(model, "precision", None) != "auto" or not (dist.is_available() and dist.is_initialized()):
-        return prec
-    from .DISTS_pytorch.DISTS_pt import AUTO_MIN_PIXELS, LADDER
+        return model.precision_for(h, w, device)
+    from .DISTS_pytorch.DISTS_pt import AUTO_MIN_PIXELS, size_class
     if h * w < AUTO_MIN_PIXELS:
-        return prec  # always f32s, nothing to agree on
-    t = torch.tensor([LADDER.index(prec)], dtype=torch.int32, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)  # LADDER is ordered fastest -> most accurate
-    agreed = LADDER[int(t.item())]
-    report = model.calibrate(device, h, w)  # (the cached report of this size class: what precision_for reads)
-    if agreed != prec:
-        report["choice_local"], report["choice"] = prec, agreed
-    report["agreed_over_ranks"] = dist.get_world_size(group)
+        return model.precision_for(h, w, device)  # always f32s, nothing to agree on
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    box = [None]
+    if rank == 0:
+        choice = model.precision_for(h, w, device)  # (the live-alpha/beta verdict where that applies)
+        box[0] = (choice, dict(model.calibrate(device, h, w)))
+    # (an object broadcast: a few hundred bytes of pickled report; gloo and RCCL alike)
+    on_gpu = torch.device(device).type == "cuda" and dist.get_backend(group) == "nccl"  # (RCCL moves device buffers only)
+    dist.broadcast_object_list(box, src=0 if group is None else dist.get_global_rank(group, 0), group=group,
+                               device=torch.device(device) if on_gpu else None)
+    agreed, report = box[0]
+    report = dict(report)
+    report["choice_rank0_calibration"], report["choice"] = report.get("choice"), agreed
+    report["agreed_over_ranks"], report["source"] = world, report.get("source", "?") + (" (rank 0)" if rank else "")
+    if hasattr(model, "_agreed"):
+        cls = max(size_class(h, w), 0)
+        model._agreed[cls] = (model._weights_key(torch.device(device)), agreed)
+        model._agreed_report = report
     return agreed

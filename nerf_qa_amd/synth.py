@@ -92,6 +92,63 @@ def _box5(x: np.ndarray) -> np.ndarray:
 
 
 KINDS = ("noise02", "noise10", "blur", "indep", "same")
+# NeRF-render-like content (round 4): constant backgrounds, smooth regions, flat frames with floaters -- the regime
+# that produces nearly dead VGG channels (what the 16-bit modes' outliers and A-DISTS' knife edge are made of), which
+# the full-frame-texture families above never reach (a reference script feeds exactly such frames: prep.py:181-198)
+NERF_KINDS = ("nerf_white", "nerf_black", "nerf_grad", "nerf_float")
+
+
+def _object_mask(seed: int, h: int, w: int, frac_lo=0.3, frac_hi=0.6) -> np.ndarray:
+    """A soft-edged union of two ellipses covering frac_lo..frac_hi of the frame ((1,1,h,w) float64 in [0,1]): the
+    'object' of a synthetic NeRF scene; everything else is constant background."""
+    u = uniform(seed, 12, stream=21)
+    yy, xx = np.meshgrid(np.arange(h, dtype=np.float64) / h, np.arange(w, dtype=np.float64) / w, indexing="ij")
+    frac = frac_lo + (frac_hi - frac_lo) * u[0]
+    m = np.zeros((h, w))
+    for k in range(2):
+        cy, cx = 0.35 + 0.3 * u[1 + 5 * k], 0.35 + 0.3 * u[2 + 5 * k]
+        ry = np.sqrt(frac / 2.0 / np.pi) * (0.8 + 0.6 * u[3 + 5 * k])
+        rx = frac / 2.0 / np.pi / ry
+        d = ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2
+        m = np.maximum(m, np.clip((1.0 - d) * 12.0, 0.0, 1.0))  # ~2-3 pixels of anti-aliased rim at 256 x 256
+    return m[None, None]
+
+
+def _nerf_pair(seed: int, h: int, w: int, kind: str):
+    n = 3 * h * w
+    yy, xx = np.meshgrid(np.arange(h, dtype=np.float64), np.arange(w, dtype=np.float64), indexing="ij")
+    ph = uniform(seed, 6, stream=8) * 2.0 * np.pi
+    low = np.stack([0.5 + 0.5 * np.sin(xx * (0.05 + 0.01 * c) + ph[c]) * np.cos(yy * (0.04 + 0.013 * c) + ph[3 + c])
+                    for c in range(3)])[None]
+    tex = 0.5 * uniform(seed, n, stream=7).reshape(1, 3, h, w) + 0.5 * low
+    if kind in ("nerf_white", "nerf_black"):
+        bg = 1.0 if kind == "nerf_white" else 0.0
+        m = _object_mask(seed, h, w)
+        x = m * tex + (1.0 - m) * bg
+        # the render: the object slightly blurred and noisy, the background EXACTLY the constant (as a NeRF's
+        # white / black background is), the silhouette a little off (mask of another seed-derived shape blended in)
+        m2 = np.clip(m + 0.15 * (_object_mask(seed + 7919, h, w, 0.3, 0.6) - m), 0.0, 1.0)
+        obj = _box5(tex) * 0.5 + tex * 0.5 + 0.03 * normal(seed, n, stream=9).reshape(tex.shape)
+        y = np.clip(m2 * obj + (1.0 - m2) * bg, 0.0, 1.0)
+    elif kind == "nerf_grad":
+        # smooth everywhere: a low-frequency pattern, no per-pixel noise; the render is brighter / softer
+        u = uniform(seed, 2, stream=22)
+        x = low
+        y = np.clip(_box5(low) * (0.9 + 0.2 * u[0]) + 0.04 * (u[1] - 0.5), 0.0, 1.0)
+    elif kind == "nerf_float":
+        # a flat frame (one colour, a faint gradient) and a render with a handful of small blobs ('floaters')
+        u = uniform(seed, 64, stream=23)
+        col = 0.2 + 0.6 * u[:3]
+        x = col[None, :, None, None] + 0.05 * (low - 0.5)
+        y = x.copy()
+        for k in range(6):
+            cy, cx, r = u[4 + 6 * k] * h, u[5 + 6 * k] * w, 2.0 + u[6 + 6 * k] * 0.04 * min(h, w)
+            blob = np.clip(1.5 - np.sqrt((yy - cy) ** 2 + (xx - cx) ** 2) / r, 0.0, 1.0)[None, None]
+            y = (1.0 - blob) * y + blob * u[7 + 6 * k:10 + 6 * k][None, :, None, None]
+        x, y = np.clip(x, 0.0, 1.0), np.clip(y, 0.0, 1.0)
+    else:
+        raise ValueError(f"unknown distortion kind {kind!r}")
+    return x.astype(np.float32), y.astype(np.float32)
 
 
 def frame_pair(seed: int, h: int, w: int, kind: str = "noise10"):
@@ -102,6 +159,8 @@ def frame_pair(seed: int, h: int, w: int, kind: str = "noise10"):
     additive Gaussian noise (sigma .02 / .1), a 5x5 box blur, an independent
     image, or x itself.
     """
+    if kind in NERF_KINDS:
+        return _nerf_pair(seed, h, w, kind)
     n = 3 * h * w
     base = uniform(seed, n, stream=7).reshape(1, 3, h, w)
     yy, xx = np.meshgrid(np.arange(h, dtype=np.float64), np.arange(w, dtype=np.float64), indexing="ij")

@@ -94,6 +94,12 @@ def score_video(ref: torch.Tensor, render: torch.Tensor, dists_model: Optional[t
         return scores.cpu().numpy()
 
     frames = {}
+    if dists_model is not None and getattr(dists_model, "precision", None) == "auto" and policy is None:
+        # one precision mode per video: under a process group rank 0's calibration verdict is broadcast BEFORE the
+        # shards are scored (ranks whose shard is empty never enter forward(), so the collective cannot live there);
+        # with no process group this is the plain precision_for.  (With `policy` the prepared size is only known per
+        # batch; callers who shard prepared-on-the-fly videos call sharding.agree_precision with that size themselves.)
+        sharding.agree_precision(dists_model, int(ref.shape[-2]), int(ref.shape[-1]), ref.device, group)
     if adists_model is not None:
         frames["A-DISTS"] = run(lambda a, b: adists_model(a, b, as_loss=False))
         out.update(video_columns("A-DISTS", frames["A-DISTS"], suffix))

@@ -2,7 +2,8 @@
 """Pin the oracle against the reference itself and freeze golden vectors.
 
 AUTHORING-CONTAINER ONLY (needs /root/reference).  Run:  python -m oracle.make_goldens [part ...]
-parts: small (seconds), full (BASELINE.json's full-size configs, ~10 min of CPU), variants, video; default all.
+parts: small (seconds), full (BASELINE.json's full-size configs, ~15 min of CPU), variants, video, nerf (NeRF-like
+content families, ~1 min); default all.  (full1080g13: only round 4's addition to `full`.)
 
 What it does
   1. puts oracle/_standin (a local `torchvision` stand-in; the real package is not
@@ -79,7 +80,7 @@ def published_alpha_beta():
 # gain 1.3 (relu5_3 mean ~10, max ~120 -- the ImageNet-like magnitude) is added for the cheap 256x256 batch.
 FULL_DISTS = [
     ("b32_256", 256, 256, tuple(range(200, 232)), None, (1.0, 1.3, 1.6)),
-    ("1080p", 1080, 1920, (300, 301, 302), ("blur", "noise10", "indep"), (1.0, 1.6)),
+    ("1080p", 1080, 1920, (300, 301, 302), ("blur", "noise10", "indep"), (1.0, 1.3, 1.6)),  # (1.3 added in round 4)
 ]
 FULL_ADISTS = [
     ("b8_256", 256, 256, tuple(range(240, 248)), None, (1.0, 1.6)),
@@ -91,17 +92,56 @@ def gain_tag(gain):
     return "" if gain == 1.0 else "_g%d" % round(gain * 10)
 
 
-def fullsize_goldens(gold):
+# ---- NeRF-render-like content (round 4): constant backgrounds, smooth frames, floaters ---------
+# 12 pairs of 256x256 per weight set (three of each synth.NERF_KINDS family), DISTS and A-DISTS, from the reference.
+NERF_SEEDS = tuple(range(400, 412))
+
+
+def nerf_goldens(gold, only_gain=None):
+    alpha, beta = published_alpha_beta()
+    for gain in (1.0, 1.3, 1.6):
+        if only_gain is not None and gain != only_gain:
+            continue
+        RefDISTS, RefADISTS, np_convs = import_reference(gain)
+        convs = dists_oracle.convs_from_numpy(np_convs)
+        ref_d = RefDISTS(load_weights=False).eval()
+        ref_d.alpha.data, ref_d.beta.data = alpha.clone(), beta.clone()
+        ref_a = RefADISTS().eval()
+        kinds = [synth.NERF_KINDS[i % 4] for i in range(len(NERF_SEEDS))]
+        xn, yn = synth.frame_batch(NERF_SEEDS, 256, 256, kinds)
+        x, y = torch.from_numpy(xn), torch.from_numpy(yn)
+        with torch.no_grad():
+            r = ref_d(x, y)
+            f0, f1 = dists_oracle.vgg_pyramid(x, convs), dists_oracle.vgg_pyramid(y, convs)
+            s1, s2 = dists_oracle.dists_stats(f0, f1)
+            o = dists_oracle.dists_score(s1, s2, alpha, beta)
+            ra = ref_a(x, y, as_loss=False)
+            oa = adists_oracle.adists(x, y, convs, as_loss=False)
+        d, da = (o - r).abs().max().item(), (oa - ra).abs().max().item()
+        assert d <= 2e-6 and da <= 2e-6, f"nerf families gain {gain}: oracle differs from the reference by {d} / {da}"
+        # dead channels per tap on these frames (what the family is for): fraction of (pair, channel) with a zero variance
+        dead = [float(((f.flatten(2).var(2, unbiased=False) < 1e-12).float().mean())) for f in f0[1:]]
+        np.savez(os.path.join(gold, f"nerf_256{gain_tag(gain)}.npz"), h=256, w=256, seeds=np.array(NERF_SEEDS),
+                 kinds=np.array(kinds), weight_seed=WEIGHT_SEED, weight_gain=gain, score=r.numpy(), s1=s1.numpy(),
+                 s2=s2.numpy(), adists=ra.numpy(), dead_frac=np.array(dead))
+        print(f"nerf families gain {gain}: DISTS {np.round(r.numpy(), 4).tolist()} |oracle-ref|={d:.1e}; "
+              f"A-DISTS {np.round(ra.numpy(), 4).tolist()} |oracle-ref|={da:.1e}; dead-channel fraction per tap {np.round(dead, 3).tolist()}",
+              flush=True)
+
+
+def fullsize_goldens(gold, only=None):
     alpha, beta = published_alpha_beta()
     import time
     for gain in (1.0, 1.3, 1.6):
+        if only and gain != only[1]:
+            continue
         RefDISTS, RefADISTS, np_convs = import_reference(gain)
         convs = dists_oracle.convs_from_numpy(np_convs)
         ref_d = RefDISTS(load_weights=False).eval()
         ref_d.alpha.data, ref_d.beta.data = alpha.clone(), beta.clone()
         ref_a = RefADISTS().eval()
         for name, h, w, seeds, kinds, gains in FULL_DISTS:
-            if gain not in gains:
+            if gain not in gains or (only and name != only[0]):
                 continue
             scores, s1s, s2s, summ = [], [], [], []
             for i, seed in enumerate(seeds):
@@ -126,7 +166,7 @@ def fullsize_goldens(gold):
                      kinds=np.array(kk), weight_seed=WEIGHT_SEED, weight_gain=gain, score=np.concatenate(scores),
                      s1=np.concatenate(s1s), s2=np.concatenate(s2s), feat_x=np.array(summ))
         for name, h, w, seeds, kinds, gains in FULL_ADISTS:
-            if gain not in gains:
+            if gain not in gains or only:
                 continue
             scores = []
             for i, seed in enumerate(seeds):
@@ -293,13 +333,17 @@ def feat_summary(feats):
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(os.cpu_count())
-    parts = set(sys.argv[1:]) or {"small", "full", "variants", "video"}
+    parts = set(sys.argv[1:]) or {"small", "full", "variants", "video", "nerf"}
     gold = os.path.join(ROOT, "tests", "golden")
     os.makedirs(gold, exist_ok=True)
     if "video" in parts:
         video_goldens(gold)
     if "full" in parts:
         fullsize_goldens(gold)
+    if "full1080g13" in parts:  # (only the file round 4 added: three 1080p pairs at gain 1.3, ~6 min of CPU)
+        fullsize_goldens(gold, only=("1080p", 1.3))
+    if "nerf" in parts:
+        nerf_goldens(gold)
     if "variants" in parts:
         import_reference()
         variant_goldens(gold)

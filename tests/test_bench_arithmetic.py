@@ -38,7 +38,10 @@ def test_workloads_name_the_baseline_configs():
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     assert "1080" in base["configs"][2] and b.WORKLOADS["1080p"]["B"] == 8 and b.WORKLOADS["1080p"]["H"] == 1080
     assert b.WORKLOADS["256"]["B"] == 32 and b.WORKLOADS["adists1080p"]["metric"] == "A-DISTS"
-    assert {k for k, _ in b.COMPANIONS} <= set(b.WORKLOADS)
+    assert {e[0] for e in b.COMPANIONS} <= set(b.WORKLOADS)
+    # the shipped default on the two other pinned weight sets and the exact-f32 mode ride on the line
+    assert ("1080p", None, "synth:1234:1.3") in b.COMPANIONS and ("1080p", None, "synth:1234:1.6") in b.COMPANIONS
+    assert ("1080p", "f32") in b.COMPANIONS
 
 
 def test_committed_traffic_summary_is_readable():

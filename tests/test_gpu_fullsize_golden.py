@@ -3,7 +3,7 @@
 CPU), at their STATED batch sizes and on two more VGG weight sets:
 
   configs[1]  B=32 of 256x256, DISTS            weight gains 1.0, 1.3, 1.6
-  configs[2]  B=8 of 1920x1080, DISTS           gains 1.0, 1.6
+  configs[2]  B=8 of 1920x1080, DISTS           gains 1.0, 1.3, 1.6
   configs[4]  B=8 of 1920x1080, A-DISTS         gains 1.0, 1.6       (+ B=8 of 256x256)
 
 The reference's result for a pair does not depend on its batch neighbours, so the golden pairs are placed at
@@ -108,7 +108,7 @@ def test_dists_b32_256_vs_reference(gain, dev):
         del m
 
 
-@pytest.mark.parametrize("gain", [1.0, 1.6])
+@pytest.mark.parametrize("gain", [1.0, 1.3, 1.6])
 def test_dists_1080p_b8_vs_reference(gain, dev):
     """configs[2] at its stated batch: B=8 of 1920x1080, golden pairs at slots 0, 3 and 7."""
     from nerf_qa_amd.DISTS_pytorch import DISTS
@@ -116,11 +116,15 @@ def test_dists_1080p_b8_vs_reference(gain, dev):
     gx, gy = _pairs(g, dev)
     slots = (0, 3, 7)
     x, y = _batch_with(gx, gy, slots, 8, dev)
-    for prec, tol in ((None, 1e-4), ("f16", 1e-4), ("f16w", 1e-4), ("f32m", 4e-5), ("f32s", 2e-5)):  # None = the shipped default (auto)
+    # (gain 1.3, "the ImageNet magnitude", pinned at 1080p since round 4: the default there is f32m; forced f16 / f16w are
+    # out of spec at that gain by the calibration's own verdict and only printed)
+    loose = gain == 1.3
+    for prec, tol in ((None, 1e-4), ("f16", None if loose else 1e-4), ("f16w", None if loose else 1e-4), ("f32m", 4e-5),
+                      ("f32s", 2e-5)):  # None = the shipped default (auto)
         m = DISTS(precision=prec, vgg16_path=_spec(gain)).to(dev).eval()
         if prec is None:
             chosen = m.precision_for(1080, 1920, dev)  # class 3: 224 pairs of 720p + 32 of 1080p through every rung
-            assert chosen == {1.0: "f16", 1.6: "f32s"}[gain], m.calibrate(dev, 1080, 1920)
+            assert chosen == {1.0: "f16", 1.3: "f32m", 1.6: "f32s"}[gain], m.calibrate(dev, 1080, 1920)
             prec = "auto->" + chosen
         with torch.no_grad():
             got = m(x, y)
@@ -132,7 +136,7 @@ def test_dists_1080p_b8_vs_reference(gain, dev):
         e2 = np.abs(s2[list(slots)].cpu().numpy() - g["s2"]).max()
         print(f"\nDISTS B=8 1080p gain {gain} {prec}: got {sel} ref {g['score']} max|dscore|={err:.2e} "
               f"max|dS1|={e1:.2e} max|dS2|={e2:.2e}")
-        assert err <= tol, (prec, gain, err)
+        assert err <= (tol if tol else 5e-4), (prec, gain, err)
         del m
         torch.cuda.empty_cache()
 
@@ -169,6 +173,46 @@ def test_adists_b8_256_vs_reference(gain, dev):
     err = np.abs(got - g["score"]).max()
     print(f"\nA-DISTS B=8 256x256 gain {gain} f32s: max|dscore|={err:.2e}")
     assert err <= 1e-4, (gain, err)
+
+
+@pytest.mark.parametrize("gain", [1.0, 1.3, 1.6])
+def test_nerf_like_content_vs_reference(gain, dev):
+    """NeRF-render-like frames (round 4): constant white / black backgrounds over 40-70 % of the
+    frame, smooth gradients, flat frames with floaters -- 12 pairs of 256x256 per weight set, goldens from the imported
+    reference (oracle/make_goldens.py `nerf`).  2-4.5 % of their (pair, channel) statistics have EXACTLY zero variance,
+    the regime of the 16-bit modes' outliers and of A-DISTS' knife edge, which the full-frame-texture families never
+    reach.  The shipped defaults of both metrics must hold 1e-4; every explicitly named DISTS rung is printed."""
+    from nerf_qa_amd import synth
+    from nerf_qa_amd.ADISTS import ADISTS
+    from nerf_qa_amd.DISTS_pytorch import DISTS
+    from nerf_qa_amd.DISTS_pytorch.DISTS_pt import LADDER
+    tag = "" if gain == 1.0 else "_g%d" % round(gain * 10)
+    g = np.load(os.path.join(GOLDEN, f"nerf_256{tag}.npz"))
+    xn, yn = synth.frame_batch([int(s) for s in g["seeds"]], 256, 256, [str(k) for k in g["kinds"]])
+    x, y = torch.from_numpy(xn).to(dev), torch.from_numpy(yn).to(dev)
+    m = DISTS(vgg16_path=_spec(gain)).to(dev).eval()
+    with torch.no_grad():
+        got = m(x, y).cpu().numpy()
+    chosen = m.precision_for(256, 256, dev)
+    err = np.abs(got - g["score"]).max()
+    print(f"\nNeRF-like content gain {gain}: DISTS default (auto -> {chosen}) max|dscore|={err:.2e} "
+          f"(scores {g['score'].min():.4f}..{g['score'].max():.4f}; dead (pair, channel) fraction per tap {g['dead_frac'].round(3).tolist()})")
+    assert err <= 1e-4, (gain, chosen, err)
+    del m
+    for prec in LADDER + ("f32",):
+        mm = DISTS(precision=prec, vgg16_path=_spec(gain)).to(dev).eval()
+        with torch.no_grad():
+            e = np.abs(mm(x, y).cpu().numpy() - g["score"])
+        print(f"   {prec:6s}: max|dscore|={e.max():.2e} at {g['kinds'][int(e.argmax())]}")
+        if prec in ("f32s", "f32"):  # (3.6e-6 on the flat-plus-floaters pairs in BOTH: exactly dead channels, summation order)
+            assert e.max() <= 1e-5, (prec, gain, e.max())
+        del mm
+    a = ADISTS(vgg16_path=_spec(gain)).to(dev).eval()
+    with torch.no_grad():
+        agot = a(x, y, as_loss=False).cpu().numpy()
+    aerr = np.abs(agot - g["adists"])
+    print(f"   A-DISTS default (auto -> {a.precision_for(256, 256)}): max|dscore|={aerr.max():.2e} at {g['kinds'][int(aerr.argmax())]}")
+    assert aerr.max() <= 1e-4, (gain, aerr)
 
 
 @pytest.mark.parametrize("h,w,prec", [(1080, 1920, "f32s"), (1080, 1920, "f16"), (1080, 1920, "f32m"), (2160, 3840, "f16")],

@@ -123,3 +123,24 @@ def test_oracle_matches_full_size_goldens_256(path):
         a, b = (torch.from_numpy(d[k]).view(1, -1, 1, 1) for k in ("alpha", "beta"))
         got = dists_oracle.dists(x, y, convs, a, b).numpy()
     assert np.abs(got - g["score"][:n]).max() <= 2e-6
+
+
+NERF_256 = sorted(glob.glob(os.path.join(GOLDEN, "nerf_256*.npz")))
+
+
+@pytest.mark.parametrize("path", NERF_256, ids=[os.path.basename(p)[:-4] for p in NERF_256])
+def test_oracle_matches_nerf_like_goldens(path):
+    """NeRF-render-like content (constant backgrounds, gradients, floaters; make_goldens `nerf`): one pair of each
+    family per weight set through both oracles against the reference's frozen scores."""
+    from nerf_qa_amd import synth
+    from oracle import adists_oracle, dists_oracle
+    g = np.load(path)
+    assert sorted(set(str(k) for k in g["kinds"])) == sorted(synth.NERF_KINDS) and len(g["seeds"]) == 12
+    convs = dists_oracle.convs_from_numpy(synth.vgg16_weights(int(g["weight_seed"]), float(g["weight_gain"])))
+    xn, yn = synth.frame_batch([int(s) for s in g["seeds"][:4]], 256, 256, [str(k) for k in g["kinds"][:4]])
+    x, y = torch.from_numpy(xn), torch.from_numpy(yn)
+    d = np.load(os.path.join(os.path.dirname(GOLDEN), "..", "nerf_qa_amd", "data", "dists_alpha_beta.npz"))
+    a, b = (torch.from_numpy(d[k]).view(1, -1, 1, 1) for k in ("alpha", "beta"))
+    assert np.abs(dists_oracle.dists(x, y, convs, a, b).numpy() - g["score"][:4]).max() <= 2e-6
+    assert np.abs(adists_oracle.adists(x[:2], y[:2], convs, as_loss=False).numpy() - g["adists"][:2]).max() <= 2e-6
+    assert (g["dead_frac"] > 0.01).all()  # the family does what it is for: exactly dead channels in every tap

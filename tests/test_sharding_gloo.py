@@ -133,30 +133,44 @@ def _agree_worker(rank, world, port, choices, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from nerf_qa_amd import sharding
 
-    class Model:  # what agree_precision touches of a DISTS module: its calibration report of the frame's size class
+    class Model:  # what agree_precision touches of a DISTS module
         precision = "auto"
 
         def __init__(self, choice):
-            self.report = {"choice": choice}
+            self.report = {"choice": choice, "source": "measured"}
+            self._agreed = {}
+            self.calibrations = 0
+
+        def _weights_key(self, device):
+            return ("stub", str(device))
 
         def precision_for(self, h, w, device=None):
-            return "f32s" if h * w < 128 * 128 else self.report["choice"]
+            if self.precision != "auto":
+                return self.precision
+            if h * w < 128 * 128:
+                return "f32s"
+            hit = self._agreed.get(3)
+            return hit[1] if hit else self.calibrate(device, h, w)["choice"]
 
         def calibrate(self, device, h, w):
+            self.calibrations += 1
             return self.report
 
     m = Model(choices[rank])
     got = sharding.agree_precision(m, 1080, 1920, torch.device("cpu"))
+    ncal = m.calibrations
     small = sharding.agree_precision(m, 64, 64, torch.device("cpu"))
     named = Model(choices[rank])
     named.precision = "f16"
-    q.put((rank, got, m.precision_for(1080, 1920), m.report, small, sharding.agree_precision(named, 1080, 1920, torch.device("cpu"))))
+    q.put((rank, got, m.precision_for(1080, 1920), m._agreed_report, small,
+           sharding.agree_precision(named, 1080, 1920, torch.device("cpu")), ncal))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("choices,want", [(("f16", "f32m"), "f32m"), (("f32s", "f16w"), "f32s"), (("f16", "f16"), "f16")])
-def test_ranks_agree_on_the_most_accurate_auto_choice(choices, want):
-    """bench.py --gpus N / the video harness: one precision mode per video whatever each rank's own calibration said."""
+@pytest.mark.parametrize("choices", [("f16", "f32m"), ("f32s", "f16w"), ("f16", "f16"), ("f32m", "f16", "f32s")])
+def test_rank0_calibrates_and_every_rank_adopts_its_verdict(choices):
+    """bench.py --gpus N / the video harness: one precision mode per video.  Rank 0's calibration verdict is broadcast
+    (round 4); the other ranks run NO calibration of their own, whatever theirs would have said."""
     world = len(choices)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -168,7 +182,8 @@ def test_ranks_agree_on_the_most_accurate_auto_choice(choices, want):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, got, after, report, small, named in results:
-        assert got == want and after == want and report["agreed_over_ranks"] == world
-        assert report.get("choice_local", want) == choices[rank]
-        assert small == "f32s" and named == choices[rank]  # nothing to agree on: tiny frames, named precision
+    want = choices[0]
+    for rank, got, after, report, small, named, ncal in results:
+        assert got == want and after == want and report["agreed_over_ranks"] == world and report["choice"] == want
+        assert ncal == (2 if rank == 0 else 0), (rank, ncal)  # (rank 0: precision_for + the report; others: nothing)
+        assert small == "f32s" and named == "f16"  # nothing to agree on: tiny frames, named precision
