@@ -206,13 +206,26 @@ int nqa_resize_pil_bilinear_u8(const uint8_t *in, int n, int Hin, int Win, int H
 
 /* ---- tuning hook ------------------------------------------------------------------ */
 
+/* The stage-closing conv of the DISTS path fused with what consumes its tap (nqa_conv_pool.hip; replaces
+ * nerf_qa/DISTS_pytorch/DISTS_pt.py:94 `stage2` conv2_2 + ReLU, :22-25 the L2pooling in front of stage 3, and the
+ * sums behind :130-142 for tap relu2_2): the tap is never written.  `in`: dev NHWC batch of 2B images of `layer`'s input
+ * (x images [0,B), y images [B,2B)), 16-bit activations of `prec`'s stage; pooled: dev (2B, ceil(H/2), ceil(W/2), Cout)
+ * in the next stage's input format; sums: dev double (B, Cout, 5) = {sum x, sum y, sum x^2, sum y^2, sum xy} over the
+ * H*W pixels of the (rounded) tap, per pair and channel.  Only layer 3 (conv2_2) in NQA_PREC_F16 and the mixed modes
+ * whose stage 3 stays 16-bit has a fused form so far: anything else returns NQA_E_SHAPE.  nqa_dists_forward takes this
+ * path by itself (nqa_set_conv_variant + 64 turns it off); these two entry points exist for tests and tools. */
+size_t nqa_conv_pool_workspace_bytes(int B, int H, int W, int layer);
+int nqa_conv_pool_stats(const void *in, int B, int H, int W, int layer, const void *packed, int prec, void *pooled,
+                        double *sums, void *ws, size_t ws_bytes, void *stream);
+
 /* Block-tile choice of the implicit-GEMM conv: 0 = 4-wave tiles (128 ch x 128 px) on every
  * layer, 1 (default) = + 8-wave 256 ch x 256 px tiles on layers with >= 256 output channels, 2 =
  * + 8-wave 128 ch x 512 px tiles wherever the map is large enough (measured equal to 1).
  * Adding 4 selects the tile form of the fused stage-1 kernel; adding 16 selects the round-1 forms of stage 1 (the
  * persistent two-phase kernel) and of conv2_1 (the implicit GEMM) instead of the register-resident-weights kernels, and
  * in NQA_PREC_F32S the round-2 pair of stage-1 kernels (VALU conv1_1 + implicit-GEMM conv1_2) instead of the fused one,
- * adding 32 the implicit GEMM for conv2_2 / conv3_1;
+ * adding 32 the implicit GEMM for conv2_2 / conv3_1; adding 64 runs the DISTS path's tap 2 UNFUSED (conv2_2, then the
+ * pool + statistics pass over the tap it wrote) instead of conv + L2-pool + statistics in one kernel (nqa_conv_pool.hip);
  * adding 8 selects the first form of the A-DISTS window pass (every wave loads its own taps instead of sharing them
  * through LDS).  Results agree in every variant to the rounding of a different summation order inside a layer (the
  * tile variants are bit-identical); this only exists so they can be timed against each other in one process.

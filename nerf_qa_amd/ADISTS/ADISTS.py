@@ -17,10 +17,11 @@ after normalisation, and the same channel rounded to exactly dead contributes T 
 flip moves the score by a channel weight, ~5e-4 (measured; DISTS' statistics have no such edge).
 precision="f16" stays available as the opt-in fast mode (3x the throughput at 1080p).
 
-as_loss=True in the reference runs the pyramids WITH autograd (:139-141); this build has
-no VGG backward, so when a gradient would actually be needed (grad mode on and x or y requires
-grad) the call raises NotImplementedError, like DISTS(require_grad=True); otherwise the value
-1-mean(D) is returned (there is no graph to lose).  as_map=True returns the
+as_loss=True in the reference runs the pyramids WITH autograd (:139-141).  DISTS(require_grad=True) has its backward
+through the HIP pyramid since round 3 (nerf_qa_amd/autograd.py); A-DISTS' windowed pass, entropy weights and probability
+chain have none yet, so when a gradient would actually be needed (grad mode on and x or y requires grad) the call raises
+NotImplementedError; otherwise the value 1-mean(D) is returned (there is no graph to lose).  No script of the reference
+calls it that way (prep.py:186, test2_prep.py:151 pass as_loss=False).  as_map=True returns the
 reference's [B,B,H,W] distortion map (:163,188-193) from one extra kernel.
 """
 from __future__ import annotations

@@ -10,15 +10,17 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libnqa_hip.so")
-SOURCES = ["nqa_api.hip", "nqa_conv.hip", "nqa_pool_stats.hip", "nqa_adists.hip", "nqa_prep.hip", "nqa_backward.hip"]
+SOURCES = ["nqa_api.hip", "nqa_conv.hip", "nqa_conv_pool.hip", "nqa_pool_stats.hip", "nqa_adists.hip", "nqa_prep.hip",
+           "nqa_backward.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Rpass-analysis=kernel-resource-usage"]  # the remarks are parsed below: no hand-scheduled kernel may spill
-RESOURCES = os.path.join(HERE, "kernel_resources.json")
+RESOURCES = os.path.join(HERE, "kernel_resources.json")            # tracked: the report of the committed sources
+RESOURCES_BUILD = os.path.join(HERE, "build", "kernel_resources.json")  # what the last build in this tree measured
 # Kernels whose schedule is written against an exact register budget and counted vmcnt waits (scratch traffic shares
 # the vmcnt counter with the LDS-DMA rings, so a spill makes every counted wait over-wait): a build in which one of
 # these uses scratch FAILS.  Matched against the demangled-ish kernel name in the compiler's remark.
-NO_SCRATCH = ("conv3x3_igemm_kernel", "conv3x3_regw_kernel", "conv3x3_regw128_kernel", "conv1_regw_kernel",
+NO_SCRATCH = ("conv3x3_igemm_kernel", "conv3x3_regw_kernel", "conv3x3_regw128_kernel", "conv3x3_regw128_pool_kernel", "conv1_regw_kernel",
               "conv1_fused_kernel", "conv1_tile_kernel", "conv1_split_kernel", "conv1_regw_split_kernel", "pool_stats_kernel",
               "adists_window_lds_kernel", "adists_window_planar_kernel", "l2pool_kernel", "stats_nhwc_kernel")
 
@@ -66,7 +68,9 @@ def check_no_scratch(res: dict) -> list:
 # nqa_adists.hip: the window kernels' tap arithmetic is written as scalar float FMAs with literal-constant weights
 # (v_fmac_f32 with a 32-bit immediate); the SLP vectorizer would pair them into v_pk_*_f32, which issue at half
 # rate on gfx950 and need a {w, w} register pair built per tap
-FILE_FLAGS = {"nqa_adists.hip": ["-fno-slp-vectorize"]}
+# nqa_conv_pool.hip: the fused epilogue is written as slices of a few scalar float instructions per k-step; SLP would
+# pair instructions of DIFFERENT slices (packed f32 ops, packed conversions) and drag them out of the MFMAs' shadow
+FILE_FLAGS = {"nqa_adists.hip": ["-fno-slp-vectorize"], "nqa_conv_pool.hip": ["-fno-slp-vectorize"]}
 
 
 def source_hash() -> str:
@@ -90,8 +94,14 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str | None = None) -> str:
+def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str | None = None,
+          emit_resources: bool = False) -> str:
     """Compile every HIP source and link the shared library; returns its path.
+
+    The per-kernel register / LDS / scratch report of a product build goes to nerf_qa_amd/build/kernel_resources.json
+    (git-ignored); the TRACKED nerf_qa_amd/kernel_resources.json is rewritten only with emit_resources=True
+    (`python -m nerf_qa_amd.build --force --emit-resources`), so a plain rebuild leaves the tree clean (ADVICE r3);
+    tests/test_cpu_lib.py compares the two when a fresh report exists.
 
     extra_flags/out build a development variant (e.g. -DNQA_ABLATE_NO_DMA for timing-only
     ablations) next to the product library; NQA_LIB selects it at load time.
@@ -128,8 +138,10 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str |
     if spills and not extra_flags:  # (timing-only ablation builds may do what they like)
         raise RuntimeError("libnqa_hip.so: hand-scheduled kernels spill to scratch:\n  " + "\n  ".join(spills))
     if not variant:
-        with open(RESOURCES, "w") as f:
-            json.dump({k: resources[k] for k in sorted(resources)}, f, indent=0)
+        os.makedirs(os.path.dirname(RESOURCES_BUILD), exist_ok=True)
+        for path in [RESOURCES_BUILD] + ([RESOURCES] if emit_resources else []):
+            with open(path, "w") as f:
+                json.dump({k: resources[k] for k in sorted(resources)}, f, indent=0)
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib]
     subprocess.run(cmd, check=True)
     if variant:  # a development variant's objects are not reused: do not let them pile up
@@ -142,4 +154,4 @@ if __name__ == "__main__":
     flags = [a for a in sys.argv[1:] if a.startswith("-D")]
     outs = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--out=")]
     print(build(force="--force" in sys.argv, verbose=True, extra_flags=flags,
-                out=os.path.join(HERE, outs[0]) if outs else None))
+                out=os.path.join(HERE, outs[0]) if outs else None, emit_resources="--emit-resources" in sys.argv))

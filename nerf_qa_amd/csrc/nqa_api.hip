@@ -223,9 +223,15 @@ static size_t act_bytes(int n, int H, int W, int prec) {
 // on_tap(k, tap, Hk, Wk, Ck, pool_dst) is called once that conv is enqueued; pool_dst is where
 // the stage's L2-pool output must go (null after stage 5).  It returns 1 if it pooled the tap
 // itself (the fused pool+statistics pass), 0 to have the plain L2-pool run, <0 on error.
-template <typename F>
+// fuse_tap(k, in, Hk, Wk, layer, pool_dst): the DISTS path's offer to run stage k's LAST conv, its L2-pool and its
+// statistics as one kernel (nqa_conv_pool.hip); it returns 1 if it did, 0 to decline (then the conv, on_tap and the
+// pool run as usual), < 0 on error.  Only asked when the batch is x | y pairs (n == 2 * nx) and no taps are wanted.
+struct NoFuse {
+  int operator()(int, const void *, int, int, int, void *) const { return 0; }
+};
+template <typename F, typename FU = NoFuse>
 static int run_stages(const float *x, const float *y, int nx, void *bufA, void *bufB, int n, int H, int W,
-                      const void *packed, int prec, void *const *taps, F on_tap, hipStream_t st) {
+                      const void *packed, int prec, void *const *taps, F on_tap, hipStream_t st, FU fuse_tap = FU()) {
   const PyrDims d = pyr_dims(H, W);
   void *cur = bufA;
   int rc;
@@ -243,6 +249,13 @@ static int run_stages(const float *x, const float *y, int nx, void *bufA, void *
       const ConvSpec &cs = kConvs[layer];
       const int k = cs.stage, kp = stage_prec(prec, k);
       void *dst = (cs.last && taps) ? taps[k] : (cur == bufA ? bufB : bufA);
+      if (cs.last && k < 4 && !taps && n == 2 * nx && layer > 1) {
+        if ((rc = fuse_tap(k, cur, d.h[k], d.w[k], layer, dst)) < 0) return rc;
+        if (rc == 1) {  // conv + pool + statistics done: `dst` holds the POOLED map
+          cur = dst;
+          continue;
+        }
+      }
       if (layer == 1 && fused_m) {
         if ((rc = conv1_fused_blob(x, y, nx, n, H, W, packed, prec, dst, st))) return rc;
       } else if ((rc = conv3x3_blob(cur, n, d.h[k], d.w[k], layer, packed, prec, kp, dst, st))) {
@@ -279,6 +292,13 @@ static int run_stages(const float *x, const float *y, int nx, void *bufA, void *
     const ConvSpec &cs = kConvs[layer];
     const int k = cs.stage;
     void *dst = (cs.last && taps) ? taps[k] : (cur == bufA ? bufB : bufA);
+    if (cs.last && k < 4 && !taps && n == 2 * nx && layer > 1) {
+      if ((rc = fuse_tap(k, cur, d.h[k], d.w[k], layer, dst)) < 0) return rc;
+      if (rc == 1) {
+        cur = dst;
+        continue;
+      }
+    }
     if (layer == 1 && fused1) {
       if ((rc = fused_s ? conv1_fused_split(x, y, nx, n, H, W, packed, dst, st)
                         : conv1_fused(x, y, nx, n, H, W, packed, prec, dst, st)))
@@ -326,7 +346,8 @@ struct StatsPlan {
 };
 // `pooled[k]` = {Ho, Wo} where stage k's statistics come out of the fused pool+statistics pass
 // ({0,0}: the plain NHWC pass over HW[k]); pooled == null: every stage runs the NCHW plane kernel.
-static StatsPlan stats_plan(int B, const int *C, const int *HW, const int (*pooled)[2], int nstage, int prec) {
+static StatsPlan stats_plan(int B, const int *C, const int *HW, const int (*pooled)[2], int nstage, int prec,
+                            const bool *fused = nullptr) {
   StatsPlan p;
   memset(&p, 0, sizeof(p));
   long off = 0;
@@ -337,6 +358,8 @@ static StatsPlan stats_plan(int B, const int *C, const int *HW, const int (*pool
     int nblk;
     if (nchw)
       nblk = cdiv(HW[k], stats_nchw_ppb(HW[k]));
+    else if (fused && fused[k])
+      nblk = NQA_FUSED_PART_BLOCKS;  // (one row per block of the fused conv + pool + statistics kernel; unwritten rows are zero)
     else if (pooled[k][0])
       nblk = pool_stats_tiles(pooled[k][0], pooled[k][1], C[k], kp, B, nullptr, nullptr);
     else
@@ -365,13 +388,14 @@ int nqa_version(void) { return NQA_VERSION; }
 const char *nqa_last_error(void) { return g_err; }
 
 int nqa_set_conv_variant(int variant) {
-  if (variant < 0 || variant > 63 || (variant & 3) == 3) {
+  if (variant < 0 || variant > 127 || (variant & 3) == 3) {
     set_error("set_conv_variant: unknown variant %d", variant);
     return NQA_E_ARG;
   }
   set_conv_variant(variant & 7);
   set_adists_window_legacy((variant & 8) != 0);
   set_conv_first_forms((variant >> 4) & 3);
+  set_fuse_taps((variant & 64) ? 0 : 1);
   return NQA_OK;
 }
 
@@ -662,9 +686,19 @@ int nqa_nhwc_to_nchw_f32(const void *in, int n, int H, int W, int C, int prec, f
 
 // Statistics plan of the fused DISTS path: stage 0 from the raw images (NCHW kernel), taps 1..4
 // inside the fused pool+statistics pass (items = pooled pixels), tap 5 by the plain NHWC pass.
-static StatsPlan dists_stats_plan(int B, int H, int W, int prec) {
+// which taps (index 1..5 of the statistics plan) the DISTS path runs fused with their conv (nqa_conv_pool.hip)
+static void dists_fused_taps(int B, int H, int W, int prec, bool fused[6]) {
+  const PyrDims d = pyr_dims(H, W);
+  for (int k = 0; k < 6; ++k) fused[k] = false;
+  fused[2] = conv_pool_fusable(3, B, d.h[1], d.w[1], prec, stage_prec(prec, 1));
+}
+static StatsPlan dists_stats_plan(int B, int H, int W, int prec, bool allow_fused = true) {
   const PyrDims d = pyr_dims(H, W);
   int C[6], HW[6], pooled[6][2];
+  bool fused[6];
+  dists_fused_taps(B, H, W, prec, fused);
+  if (!allow_fused)
+    for (int k = 0; k < 6; ++k) fused[k] = false;
   C[0] = 3;
   HW[0] = H * W;
   pooled[0][0] = pooled[0][1] = 0;
@@ -674,13 +708,20 @@ static StatsPlan dists_stats_plan(int B, int H, int W, int prec) {
     pooled[k + 1][0] = k < 4 ? d.h[k + 1] : 0;
     pooled[k + 1][1] = k < 4 ? d.w[k + 1] : 0;
   }
-  return stats_plan(B, C, HW, pooled, 6, prec);
+  return stats_plan(B, C, HW, pooled, 6, prec, fused);
+}
+// seam planes of the fused taps (behind the statistics partials in the workspace)
+static size_t dists_seam_bytes(int B, int H, int W) {
+  const PyrDims d = pyr_dims(H, W);
+  return conv_pool_seam_bytes(B, d.h[1], d.w[1], 128);
 }
 
 size_t nqa_workspace_bytes(int n_images, int H, int W, int prec) {
   if (n_images <= 0 || H <= 0 || W <= 0) return 0;
-  const StatsPlan p = dists_stats_plan((n_images + 1) / 2, H, W, prec);
-  return 2 * act_bytes(n_images, H, W, prec) + align_up(p.doubles * 8, 256);
+  // (sized for the fused and for the unfused form of every tap: the choice can be switched per thread, nqa_set_conv_variant)
+  const int B = (n_images + 1) / 2;
+  const size_t pa = dists_stats_plan(B, H, W, prec, true).doubles, pb = dists_stats_plan(B, H, W, prec, false).doubles;
+  return 2 * act_bytes(n_images, H, W, prec) + align_up((pa > pb ? pa : pb) * 8, 256) + dists_seam_bytes(B, H, W);
 }
 
 int nqa_vgg_pyramid(const float *x, int n, int H, int W, const void *packed, int prec, void *ws, size_t ws_bytes,
@@ -724,6 +765,10 @@ int nqa_dists_forward(const float *x, const float *y, int B, int H, int W, const
   char *bufA = static_cast<char *>(ws), *bufB = bufA + ab;
   double *part = reinterpret_cast<double *>(bufB + ab);
   const StatsPlan p = dists_stats_plan(B, H, W, prec);
+  const size_t pa = p.doubles, pb = dists_stats_plan(B, H, W, prec, false).doubles;
+  float *seam = reinterpret_cast<float *>(reinterpret_cast<char *>(part) + align_up((pa > pb ? pa : pb) * 8, 256));
+  bool fused[6];
+  dists_fused_taps(B, H, W, prec, fused);
   int rc;
   // feature 0 is the raw image (DISTS_pt.py:103): statistics straight from the inputs
   if ((rc = stats_nchw(x, y, B, 3, H * W, part + p.d.part_off[0], st))) return rc;
@@ -739,7 +784,12 @@ int nqa_dists_forward(const float *x, const float *y, int B, int H, int W, const
                                  : pool_stats(tap, B, hk, wk, ck, kp, pool_dst, pk, st);
         return rc2 ? rc2 : 1;
       },
-      st);
+      st,
+      [&](int k, const void *inp, int hk, int wk, int layer, void *pool_dst) {
+        if (!fused[k + 1]) return 0;
+        const int rc2 = conv_pool_stats_fused(inp, B, hk, wk, layer, packed, prec, pool_dst, seam, part + p.d.part_off[k + 1], st);
+        return rc2 ? rc2 : 1;
+      });
   if (rc) return rc;
   return finalize(part, p.d, B, s1, s2, st);
 }
@@ -778,6 +828,53 @@ int nqa_dists_stats_nchw(const float *const fx[NQA_NUM_TAPS], const float *const
   for (int k = 0; k < 6; ++k)
     if ((rc = stats_nchw(fx[k], fy[k], B, C[k], HW[k], part + p.d.part_off[k], st))) return rc;
   return finalize(part, p.d, B, s1, s2, st);
+}
+
+// ---- conv + L2-pool + statistics as a single operator (tests, tools; the DISTS path calls the launcher directly) ----
+static __global__ void part_reduce_kernel(const double *__restrict__ part, int nblk, int C, double *__restrict__ sums, long total) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;  // (b, c, s)
+  if (idx >= total) return;
+  const long per = (long)C * 5;
+  const long b = idx / per, cs = idx - b * per;
+  double acc = 0.0;
+  for (int k = 0; k < nblk; ++k) acc += part[((size_t)b * nblk + k) * per + cs];
+  sums[idx] = acc;
+}
+
+size_t nqa_conv_pool_workspace_bytes(int B, int H, int W, int layer) {
+  if (B <= 0 || H <= 0 || W <= 0 || layer < 1 || layer >= NQA_NUM_CONVS) return 0;
+  const int C = kConvs[layer].cout;
+  return align_up((size_t)B * NQA_FUSED_PART_BLOCKS * C * 5 * sizeof(double), 256) + conv_pool_seam_bytes(B, H, W, C);
+}
+
+int nqa_conv_pool_stats(const void *in, int B, int H, int W, int layer, const void *packed, int prec, void *pooled,
+                        double *sums, void *ws, size_t ws_bytes, void *stream) {
+  if (!in || !packed || !pooled || !sums || !ws) {
+    set_error("conv_pool_stats: null pointer");
+    return NQA_E_ARG;
+  }
+  if (layer < 1 || layer >= NQA_NUM_CONVS || B <= 0 || H <= 0 || W <= 0 || !prec_valid_pyramid(prec)) {
+    set_error("conv_pool_stats: bad argument (layer %d, B %d, %d x %d, prec %d)", layer, B, H, W, prec);
+    return NQA_E_ARG;
+  }
+  const int kp = stage_prec(prec, kConvs[layer].stage);
+  if (!conv_pool_fusable(layer, B, H, W, prec, kp)) {
+    set_error("conv_pool_stats: no fused form for layer %d of a %d x %d map in precision %d (B = %d)", layer, H, W, prec, B);
+    return NQA_E_SHAPE;
+  }
+  if (ws_bytes < nqa_conv_pool_workspace_bytes(B, H, W, layer)) {
+    set_error("conv_pool_stats: workspace %zu < %zu bytes", ws_bytes, nqa_conv_pool_workspace_bytes(B, H, W, layer));
+    return NQA_E_WORKSPACE;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int C = kConvs[layer].cout;
+  double *part = static_cast<double *>(ws);
+  float *seam = reinterpret_cast<float *>(static_cast<char *>(ws) + align_up((size_t)B * NQA_FUSED_PART_BLOCKS * C * 5 * sizeof(double), 256));
+  const int rc = conv_pool_stats_fused(in, B, H, W, layer, packed, prec, pooled, seam, part, st);
+  if (rc) return rc;
+  const long total = (long)B * C * 5;
+  part_reduce_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(part, NQA_FUSED_PART_BLOCKS, C, sums, total);
+  return check_launch("part_reduce");
 }
 
 int nqa_dists_score(const float *s1, const float *s2, const float *alpha, const float *beta, int B, float *out,

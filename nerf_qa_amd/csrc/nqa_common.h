@@ -241,5 +241,13 @@ int stats_nchw(const float *fx, const float *fy, int B, int C, int HW, double *p
 int finalize(const double *part, const StageDesc &d, int B, float *s1, float *s2, hipStream_t st);
 int score(const float *s1, const float *s2, const float *alpha, const float *beta, int B, float *out, hipStream_t st);
 int nhwc_to_nchw(const void *in, int n, int HW, int C, int prec, float *out, hipStream_t st);
+// ---- conv + L2-pool + statistics in one kernel (nqa_conv_pool.hip; the DISTS path's tap 2) ----
+// rows of statistics partials a fused tap reserves per pair (= the largest grid the fused kernel runs; unwritten rows are zero)
+#define NQA_FUSED_PART_BLOCKS 256
+void set_fuse_taps(int on);
+bool conv_pool_fusable(int layer, int B, int H, int W, int blob_prec, int kprec);
+size_t conv_pool_seam_bytes(int B, int H, int W, int C);
+int conv_pool_stats_fused(const void *in, int B, int H, int W, int layer, const void *packed, int blob_prec, void *pooled,
+                          float *seam, double *part, hipStream_t st);
 
 }  // namespace nqa

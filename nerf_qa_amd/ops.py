@@ -134,6 +134,28 @@ def l2pool(inp: torch.Tensor, prec) -> torch.Tensor:
     return out
 
 
+def conv_pool_stats(inp: torch.Tensor, layer: int, packed: torch.Tensor, prec):
+    """The stage-closing conv `layer` + ReLU + L2-pool + statistics sums in ONE kernel (include/nqa.h,
+    nqa_conv_pool_stats): `inp` is the 2B-image NHWC batch of the layer's input (x images then y images); returns
+    (pooled (2B, ceil(H/2), ceil(W/2), Cout) in the next stage's input dtype, sums float64 (B, Cout, 5) = sum x, sum y,
+    sum x^2, sum y^2, sum xy over the tap's pixels).  Raises NqaError where no fused form exists (only conv2_2 so far)."""
+    p = prec_id(prec)
+    dev = _need_cuda(inp, packed)
+    assert inp.is_contiguous() and inp.shape[0] % 2 == 0
+    n, h, w, c = inp.shape
+    assert c == CONV_CIN[layer]
+    b = n // 2
+    cout = CONV_COUT[layer]
+    pooled = torch.empty((n, (h + 1) // 2, (w + 1) // 2, cout), dtype=PREC_DTYPE[_lib.stage_prec(p, CONV_STAGE[layer] + 1)]
+                         if p in _lib.MIXED_STAGES else inp.dtype, device=dev)
+    sums = torch.empty((b, cout, 5), dtype=torch.float64, device=dev)
+    nbytes = lib().nqa_conv_pool_workspace_bytes(b, h, w, layer)
+    ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
+    _call(dev, lib().nqa_conv_pool_stats, ptr(inp), b, h, w, layer, ptr(packed), p, ptr(pooled), ptr(sums), ptr(ws), ws.numel(),
+          stream_ptr(dev))
+    return pooled, sums
+
+
 def nhwc_to_nchw_f32(inp: torch.Tensor, prec) -> torch.Tensor:
     p = prec_id(prec)
     dev = _need_cuda(inp)

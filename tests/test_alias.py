@@ -73,6 +73,27 @@ def test_whole_module_pickle_round_trip(alias):
     assert back.dists_model._packed == {} and back.dists_model.precision == model.dists_model.precision
 
 
+def test_pickle_leaves_every_device_cache_behind():
+    """after a require_grad=True step the module carries ~60 MB of packed CUDA blobs (`_bwd_blobs`), and since
+    round 4 calibration deltas / a process-group agreement / memo fields; none of them may enter torch.save(model)
+    (run_nerf_qa.py:502) -- a CPU-only torch.load (reeval.py:83) could not even open the CUDA ones."""
+    from nerf_qa_amd.DISTS_pytorch import DISTS
+    m = DISTS(vgg16_path="synth:1234")
+    m.__dict__["_bwd_blobs"] = (("key",), {1: torch.zeros(4)}, torch.zeros(4))  # (what autograd._backward_blobs leaves)
+    m._deltas = {0: {"f16": (torch.zeros(2, 1475), torch.zeros(2, 1475))}}
+    m._agreed = {3: (("key",), "f32m")}
+    m._live_weights(torch.device("cpu"))
+    m._vgg_digest()
+    state = m.__getstate__()
+    assert "_bwd_blobs" not in state and "_live" not in state and "_digest" not in state and "_packed" not in state
+    assert state["_deltas"] == {} and state["_agreed"] == {} and state["_auto"] is None
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    assert len(buf.getvalue()) < 60e6  # the 58.9 MB of Conv2d weights and little else
+    back = torch.load(io.BytesIO(buf.getvalue()), weights_only=False)
+    assert back._deltas == {} and back._agreed == {} and not hasattr(back, "_bwd_blobs")
+
+
 def test_module_pickled_without_this_builds_private_fields(alias):
     """A module object written by the reference's OWN class has none of this build's private attributes
     (precision, _packed, _ws, vgg_source): __setstate__ fills them in."""

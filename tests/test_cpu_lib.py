@@ -168,3 +168,18 @@ def test_no_cpu_fallback():
     x = torch.zeros(1, 3, 8, 8)
     with pytest.raises(_lib.NqaError):
         ops.dists_forward(x, x, torch.zeros(16, dtype=torch.uint8), "f32")
+
+
+def test_tracked_kernel_resources_match_the_last_build():
+    """nerf_qa_amd/kernel_resources.json is tracked and only rewritten on request (`python -m nerf_qa_amd.build --force
+    --emit-resources`); a build in this tree leaves its own report in nerf_qa_amd/build/.  When that exists the two
+    must agree -- i.e. the committed report describes the sources as they are -- and no hand-scheduled kernel spills."""
+    import json
+    from nerf_qa_amd import build as b
+    tracked = json.load(open(b.RESOURCES))
+    assert not b.check_no_scratch(tracked)
+    if not os.path.exists(b.RESOURCES_BUILD) or os.path.getmtime(b.RESOURCES_BUILD) < max(
+            os.path.getmtime(os.path.join(b.CSRC, f)) for f in os.listdir(b.CSRC) if f.endswith((".hip", ".h"))):
+        pytest.skip("no report of a build of the current sources in this tree")
+    fresh = json.load(open(b.RESOURCES_BUILD))
+    assert fresh == tracked, sorted(k for k in set(fresh) | set(tracked) if fresh.get(k) != tracked.get(k))[:5]

@@ -2,7 +2,9 @@
 calibration size class (GPU box): how far the modes the calibration admits really stray on frames it has not seen.
 f32s itself sits within 1e-6 of the CPU oracle (tests/test_gpu_fullsize_golden.py), so the deviation from f32s IS the
 deviation from the reference to that accuracy.  Content differs from the calibration's generator on purpose: random
-noise levels, blur widths, brightness / contrast changes, block artefacts, independent frames.
+noise levels, blur widths, brightness / contrast changes, block artefacts, independent frames, and (round 4, 40 % of the
+pairs) NeRF-render-like content -- objects on exactly constant white / black backgrounds, smooth frames, flat frames with
+floaters -- i.e. the regime of exactly dead VGG channels.
 usage: python tools/gpu_stress_auto.py [pairs per gain] [gains...]"""
 import math
 import sys
@@ -27,7 +29,28 @@ def frames(g, rng, h, w):
                         mode="bilinear", align_corners=False)
     mix = float(rng.uniform(0.2, 0.9))
     x = (mix * torch.rand(1, 3, h, w, device=dev, generator=g) + (1 - mix) * low).clamp_(0, 1)
-    k = int(rng.integers(0, 6))
+    k = int(rng.integers(0, 10))
+    if k >= 6:  # NeRF-render-like content (round 4): constant backgrounds, smooth frames, flat frames with floaters
+        field = F.interpolate(torch.rand(1, 1, int(rng.integers(3, 8)), int(rng.integers(3, 8)), device=dev, generator=g),
+                              size=(h, w), mode="bicubic", align_corners=False)
+        if k in (6, 7):  # textured object on an exactly constant white / black background (40-75 % of the frame)
+            bg = 1.0 if k == 6 else 0.0
+            thr = float(rng.uniform(0.48, 0.68))
+            m = ((field - thr) * float(rng.uniform(15, 60))).clamp(0, 1)
+            m2 = ((field - thr - float(rng.uniform(-0.02, 0.02))) * 40.0).clamp(0, 1)
+            r = int(rng.choice([1, 2]))
+            obj = 0.5 * x + 0.5 * F.avg_pool2d(x, 2 * r + 1, 1, r, count_include_pad=False) \
+                + float(rng.uniform(0.0, 0.05)) * torch.randn(1, 3, h, w, device=dev, generator=g)
+            return (m * x + (1 - m) * bg).clamp_(0, 1), (m2 * obj + (1 - m2) * bg).clamp_(0, 1), "nerf"
+        if k == 8:  # smooth everywhere, render slightly brighter / softer
+            xs = low * float(rng.uniform(0.4, 0.9)) + float(rng.uniform(0.0, 0.1))
+            ys = F.avg_pool2d(xs, 5, 1, 2, count_include_pad=False) * float(rng.uniform(0.9, 1.1)) + float(rng.uniform(-0.03, 0.03))
+            return xs.clamp_(0, 1), ys.clamp_(0, 1), "nerf"
+        col = torch.rand(1, 3, 1, 1, device=dev, generator=g) * 0.6 + 0.2  # k == 9: a flat frame and floaters
+        xs = (col + 0.05 * (low - 0.5)).clamp_(0, 1)
+        blob = ((field - float(rng.uniform(0.8, 0.9))) * 60.0).clamp(0, 1)
+        ys = ((1 - blob) * xs + blob * torch.rand(1, 3, 1, 1, device=dev, generator=g)).clamp_(0, 1)
+        return xs, ys, "nerf"
     if k == 0:
         y = x + float(rng.uniform(0.005, 0.15)) * torch.randn(1, 3, h, w, device=dev, generator=g)
     elif k == 1:
@@ -45,7 +68,7 @@ def frames(g, rng, h, w):
         y = torch.rand(1, 3, h, w, device=dev, generator=g)
     else:  # a one-pixel shift plus light noise (what a slightly misregistered render looks like)
         y = torch.roll(x, (int(rng.integers(-1, 2)), 1), (2, 3)) + 0.01 * torch.randn(1, 3, h, w, device=dev, generator=g)
-    return x, y.clamp_(0, 1)
+    return x, y.clamp_(0, 1), "texture"
 
 
 worst_overall = 0.0
@@ -55,17 +78,18 @@ for gain in GAINS:
     exact = DISTS(precision="f32s", vgg16_path=spec).to(dev).eval()
     rng = np.random.default_rng(777)
     g = torch.Generator(device=dev).manual_seed(31337)
-    per = {}
+    per, fam = {}, {}
     lo, hi = math.log(128 * 128), math.log(1080 * 1920)
     for i in range(N):
         area = math.exp(rng.uniform(lo, hi))
         aspect = math.exp(rng.uniform(-0.7, 0.7))
         h = int(min(max(round(math.sqrt(area / aspect)), 64), 1200))
         w = int(min(max(round(area / h), 64), 2048))
-        x, y = frames(g, rng, h, w)
+        x, y, family = frames(g, rng, h, w)
         with torch.no_grad():
             d = abs(float(auto(x, y)) - float(exact(x, y)))
         per.setdefault(size_class(h, w), []).append((d, h, w))
+        fam.setdefault((size_class(h, w), family), []).append(d)
     for c in sorted(per):
         v = np.array([t[0] for t in per[c]])
         wd = max(per[c])
@@ -74,5 +98,6 @@ for gain in GAINS:
         print(f"gain {gain} class {c} (>= {frm} px, auto -> {mode}): {len(v)} pairs  max {v.max():.2e} (at {wd[1]}x{wd[2]})  "
               f"p99 {np.quantile(v, 0.99):.2e}  rms {np.sqrt((v * v).mean()):.2e}", flush=True)
         worst_overall = max(worst_overall, v.max())
+        print("      by content family: " + ", ".join(f"{f}: {len(fam[(c, f)])} pairs max {max(fam[(c, f)]):.2e}" for f in ("texture", "nerf") if (c, f) in fam), flush=True)
 print(f"worst |auto - f32s| over everything: {worst_overall:.2e}")
 assert worst_overall <= 1e-4
