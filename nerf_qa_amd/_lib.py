@@ -51,6 +51,7 @@ _SIGNATURES = {
     "nqa_dists_score": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "nqa_conv_pool_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "nqa_conv_pool_stats": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
+    "nqa_conv1_pool_stats": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "nqa_adists_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "nqa_adists_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _sz, _vp, _vp]),
     "nqa_adists_forward_map": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _sz, _vp, _vp, _vp]),

@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libnqa_hip.so")
-SOURCES = ["nqa_api.hip", "nqa_conv.hip", "nqa_conv_pool.hip", "nqa_pool_stats.hip", "nqa_adists.hip", "nqa_prep.hip",
+SOURCES = ["nqa_api.hip", "nqa_conv.hip", "nqa_conv_pool.hip", "nqa_conv1_pool.hip", "nqa_pool_stats.hip", "nqa_adists.hip", "nqa_prep.hip",
            "nqa_backward.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
@@ -20,7 +20,7 @@ RESOURCES_BUILD = os.path.join(HERE, "build", "kernel_resources.json")  # what t
 # Kernels whose schedule is written against an exact register budget and counted vmcnt waits (scratch traffic shares
 # the vmcnt counter with the LDS-DMA rings, so a spill makes every counted wait over-wait): a build in which one of
 # these uses scratch FAILS.  Matched against the demangled-ish kernel name in the compiler's remark.
-NO_SCRATCH = ("conv3x3_igemm_kernel", "conv3x3_regw_kernel", "conv3x3_regw128_kernel", "conv3x3_regw128_pool_kernel", "conv1_regw_kernel",
+NO_SCRATCH = ("conv3x3_igemm_kernel", "conv3x3_regw_kernel", "conv3x3_regw128_kernel", "conv3x3_regw128_pool_kernel", "conv1_pool_kernel", "conv1_regw_kernel",
               "conv1_fused_kernel", "conv1_tile_kernel", "conv1_split_kernel", "conv1_regw_split_kernel", "pool_stats_kernel",
               "adists_window_lds_kernel", "adists_window_planar_kernel", "l2pool_kernel", "stats_nhwc_kernel")
 
@@ -70,7 +70,8 @@ def check_no_scratch(res: dict) -> list:
 # rate on gfx950 and need a {w, w} register pair built per tap
 # nqa_conv_pool.hip: the fused epilogue is written as slices of a few scalar float instructions per k-step; SLP would
 # pair instructions of DIFFERENT slices (packed f32 ops, packed conversions) and drag them out of the MFMAs' shadow
-FILE_FLAGS = {"nqa_adists.hip": ["-fno-slp-vectorize"], "nqa_conv_pool.hip": ["-fno-slp-vectorize"]}
+FILE_FLAGS = {"nqa_adists.hip": ["-fno-slp-vectorize"], "nqa_conv_pool.hip": ["-fno-slp-vectorize"],
+              "nqa_conv1_pool.hip": ["-fno-slp-vectorize"]}
 
 
 def source_hash() -> str:

@@ -229,9 +229,15 @@ static size_t act_bytes(int n, int H, int W, int prec) {
 struct NoFuse {
   int operator()(int, const void *, int, int, int, void *) const { return 0; }
 };
-template <typename F, typename FU = NoFuse>
+// fuse_stage1(pool_dst): the same offer for the whole of stage 1 (nqa_conv1_pool.hip: normalisation, conv1_1, conv1_2,
+// L2-pool and the statistics of tap 1 from the raw images); 1 = done, `pool_dst` holds the pooled relu1_2.
+struct NoFuse1 {
+  int operator()(void *) const { return 0; }
+};
+template <typename F, typename FU = NoFuse, typename FS = NoFuse1>
 static int run_stages(const float *x, const float *y, int nx, void *bufA, void *bufB, int n, int H, int W,
-                      const void *packed, int prec, void *const *taps, F on_tap, hipStream_t st, FU fuse_tap = FU()) {
+                      const void *packed, int prec, void *const *taps, F on_tap, hipStream_t st, FU fuse_tap = FU(),
+                      FS fuse_stage1 = FS()) {
   const PyrDims d = pyr_dims(H, W);
   void *cur = bufA;
   int rc;
@@ -282,13 +288,18 @@ static int run_stages(const float *x, const float *y, int nx, void *bufA, void *
   // round-2 pair conv1_1_kernel (VALU, split16 out) + implicit GEMM
   const bool fused_s = prec == NQA_PREC_F32S && !mixed_stage1_unfused();
   const bool fused1 = prec_elem_bytes(prec) == 2 || fused_s;
-  if (!fused1) {
+  int first_layer = 1;
+  if (!taps && n == 2 * nx) {  // stage 1 with its pool and statistics in one kernel: the layer loop starts at conv2_1
+    if ((rc = fuse_stage1(bufA)) < 0) return rc;
+    if (rc == 1) first_layer = 2;
+  }
+  if (!fused1 && first_layer == 1) {
     if ((rc = conv1_1(x, nx, H, W, packed, prec, bufA, st))) return rc;
     if (n > nx && (rc = conv1_1(y, n - nx, H, W, packed, prec,
                                 static_cast<char *>(bufA) + (size_t)nx * H * W * 64 * prec_elem_bytes(prec), st)))
       return rc;
   }
-  for (int layer = 1; layer < NQA_NUM_CONVS; ++layer) {
+  for (int layer = first_layer; layer < NQA_NUM_CONVS; ++layer) {
     const ConvSpec &cs = kConvs[layer];
     const int k = cs.stage;
     void *dst = (cs.last && taps) ? taps[k] : (cur == bufA ? bufB : bufA);
@@ -358,8 +369,8 @@ static StatsPlan stats_plan(int B, const int *C, const int *HW, const int (*pool
     int nblk;
     if (nchw)
       nblk = cdiv(HW[k], stats_nchw_ppb(HW[k]));
-    else if (fused && fused[k])
-      nblk = NQA_FUSED_PART_BLOCKS;  // (one row per block of the fused conv + pool + statistics kernel; unwritten rows are zero)
+    else if (fused && fused[k])  // (rows per pair reserved by the fused conv + pool + statistics kernels; unwritten rows are zero)
+      nblk = k == 1 ? NQA_FUSED_PART_BLOCKS_S1 : NQA_FUSED_PART_BLOCKS;
     else if (pooled[k][0])
       nblk = pool_stats_tiles(pooled[k][0], pooled[k][1], C[k], kp, B, nullptr, nullptr);
     else
@@ -388,7 +399,7 @@ int nqa_version(void) { return NQA_VERSION; }
 const char *nqa_last_error(void) { return g_err; }
 
 int nqa_set_conv_variant(int variant) {
-  if (variant < 0 || variant > 127 || (variant & 3) == 3) {
+  if (variant < 0 || variant > 511 || (variant & 3) == 3) {
     set_error("set_conv_variant: unknown variant %d", variant);
     return NQA_E_ARG;
   }
@@ -396,6 +407,7 @@ int nqa_set_conv_variant(int variant) {
   set_adists_window_legacy((variant & 8) != 0);
   set_conv_first_forms((variant >> 4) & 3);
   set_fuse_taps((variant & 64) ? 0 : 1);
+  set_fuse_stage1(((variant & 128) ? 0 : 1) | ((variant & 256) ? 2 : 0));
   return NQA_OK;
 }
 
@@ -690,6 +702,7 @@ int nqa_nhwc_to_nchw_f32(const void *in, int n, int H, int W, int C, int prec, f
 static void dists_fused_taps(int B, int H, int W, int prec, bool fused[6]) {
   const PyrDims d = pyr_dims(H, W);
   for (int k = 0; k < 6; ++k) fused[k] = false;
+  fused[1] = conv1_pool_fusable(B, H, W, prec);
   fused[2] = conv_pool_fusable(3, B, d.h[1], d.w[1], prec, stage_prec(prec, 1));
 }
 static StatsPlan dists_stats_plan(int B, int H, int W, int prec, bool allow_fused = true) {
@@ -711,9 +724,10 @@ static StatsPlan dists_stats_plan(int B, int H, int W, int prec, bool allow_fuse
   return stats_plan(B, C, HW, pooled, 6, prec, fused);
 }
 // seam planes of the fused taps (behind the statistics partials in the workspace)
-static size_t dists_seam_bytes(int B, int H, int W) {
+static size_t dists_seam_bytes(int B, int H, int W) {  // (one area: tap 1's planes are consumed before tap 2's are written)
   const PyrDims d = pyr_dims(H, W);
-  return conv_pool_seam_bytes(B, d.h[1], d.w[1], 128);
+  const size_t s1 = conv_pool_seam_bytes(B, H, W, 64), s2 = conv_pool_seam_bytes(B, d.h[1], d.w[1], 128);
+  return s1 > s2 ? s1 : s2;
 }
 
 size_t nqa_workspace_bytes(int n_images, int H, int W, int prec) {
@@ -789,6 +803,11 @@ int nqa_dists_forward(const float *x, const float *y, int B, int H, int W, const
         if (!fused[k + 1]) return 0;
         const int rc2 = conv_pool_stats_fused(inp, B, hk, wk, layer, packed, prec, pool_dst, seam, part + p.d.part_off[k + 1], st);
         return rc2 ? rc2 : 1;
+      },
+      [&](void *pool_dst) {
+        if (!fused[1]) return 0;
+        const int rc2 = conv1_pool_stats_fused(x, y, B, H, W, packed, pool_dst, seam, part + p.d.part_off[1], st);
+        return rc2 ? rc2 : 1;
       });
   if (rc) return rc;
   return finalize(part, p.d, B, s1, s2, st);
@@ -841,10 +860,36 @@ static __global__ void part_reduce_kernel(const double *__restrict__ part, int n
   sums[idx] = acc;
 }
 
+static int fused_part_rows(int layer) { return layer == 1 ? NQA_FUSED_PART_BLOCKS_S1 : NQA_FUSED_PART_BLOCKS; }
 size_t nqa_conv_pool_workspace_bytes(int B, int H, int W, int layer) {
   if (B <= 0 || H <= 0 || W <= 0 || layer < 1 || layer >= NQA_NUM_CONVS) return 0;
   const int C = kConvs[layer].cout;
-  return align_up((size_t)B * NQA_FUSED_PART_BLOCKS * C * 5 * sizeof(double), 256) + conv_pool_seam_bytes(B, H, W, C);
+  return align_up((size_t)B * fused_part_rows(layer) * C * 5 * sizeof(double), 256) + conv_pool_seam_bytes(B, H, W, C);
+}
+
+int nqa_conv1_pool_stats(const float *x, const float *y, int B, int H, int W, const void *packed, int prec, void *pooled,
+                         double *sums, void *ws, size_t ws_bytes, void *stream) {
+  if (!x || !y || !packed || !pooled || !sums || !ws || B <= 0 || H <= 0 || W <= 0) {
+    set_error("conv1_pool_stats: bad argument");
+    return NQA_E_ARG;
+  }
+  if (!conv1_pool_fusable(B, H, W, prec)) {
+    set_error("conv1_pool_stats: no fused stage 1 for %d x %d frames in precision %d (B = %d)", H, W, prec, B);
+    return NQA_E_SHAPE;
+  }
+  if (ws_bytes < nqa_conv_pool_workspace_bytes(B, H, W, 1)) {
+    set_error("conv1_pool_stats: workspace %zu < %zu bytes", ws_bytes, nqa_conv_pool_workspace_bytes(B, H, W, 1));
+    return NQA_E_WORKSPACE;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  double *part = static_cast<double *>(ws);
+  float *seam = reinterpret_cast<float *>(static_cast<char *>(ws) +
+                                          align_up((size_t)B * NQA_FUSED_PART_BLOCKS_S1 * 64 * 5 * sizeof(double), 256));
+  const int rc = conv1_pool_stats_fused(x, y, B, H, W, packed, pooled, seam, part, st);
+  if (rc) return rc;
+  const long total = (long)B * 64 * 5;
+  part_reduce_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(part, NQA_FUSED_PART_BLOCKS_S1, 64, sums, total);
+  return check_launch("part_reduce");
 }
 
 int nqa_conv_pool_stats(const void *in, int B, int H, int W, int layer, const void *packed, int prec, void *pooled,

@@ -244,7 +244,13 @@ int nhwc_to_nchw(const void *in, int n, int HW, int C, int prec, float *out, hip
 // ---- conv + L2-pool + statistics in one kernel (nqa_conv_pool.hip; the DISTS path's tap 2) ----
 // rows of statistics partials a fused tap reserves per pair (= the largest grid the fused kernel runs; unwritten rows are zero)
 #define NQA_FUSED_PART_BLOCKS 256
+#define NQA_FUSED_PART_BLOCKS_S1 512  // (the fused stage 1 leaves two rows per block)
 void set_fuse_taps(int on);
+void set_fuse_stage1(int on);
+int pool_seam_finish(const float *seam, void *pooled, int nimg, int strips, int Ho, int Wo, int C, hipStream_t st);
+bool conv1_pool_fusable(int B, int H, int W, int blob_prec);
+int conv1_pool_stats_fused(const float *x, const float *y, int B, int H, int W, const void *packed, void *pooled, float *seam,
+                           double *part, hipStream_t st);
 bool conv_pool_fusable(int layer, int B, int H, int W, int blob_prec, int kprec);
 size_t conv_pool_seam_bytes(int B, int H, int W, int C);
 int conv_pool_stats_fused(const void *in, int B, int H, int W, int layer, const void *packed, int blob_prec, void *pooled,

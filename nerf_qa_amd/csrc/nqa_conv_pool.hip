@@ -491,6 +491,15 @@ __global__ __launch_bounds__(256) void pool_seam_kernel(const float *__restrict_
 }
 
 // ---- host side -----------------------------------------------------------------------------------------------
+// the seam pass behind a fused conv + pool kernel (f16 pooled map; also nqa_conv1_pool.hip's)
+int pool_seam_finish(const float *seam, void *pooled, int nimg, int strips, int Ho, int Wo, int C, hipStream_t st) {
+  const long total = (long)nimg * strips * Ho * (C / 4);
+  TimedLaunch t(NQA_K_POOL, st);
+  pool_seam_kernel<false><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(seam, static_cast<char *>(pooled), nimg, strips, Ho, Wo, C,
+                                                                             total);
+  return check_launch("pool_seam");
+}
+
 static int pool_num_cus() {
   static std::atomic<int> cus[64];
   int dev = 0;
@@ -568,12 +577,7 @@ static int launch_conv_pool(const void *in, int B, int H, int W, int layer, cons
     const int rc = check_launch("conv3x3_regw128_pool");
     if (rc) return rc;
   }
-  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
-  const long total = 2L * B * strips * Ho * (cout / 4);
-  TimedLaunch t(NQA_K_POOL, st);
-  pool_seam_kernel<false><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(seam, static_cast<char *>(pooled), 2 * B, strips, Ho,
-                                                                             Wo, cout, total);
-  return check_launch("pool_seam");
+  return pool_seam_finish(seam, pooled, 2 * B, strips, (H + 1) / 2, (W + 1) / 2, cout, st);
 }
 
 // conv layer 3 (conv2_2) of the 2B-image batch `in` (x images [0,B), y images [B,2B), NHWC f16, 128 channels) ->

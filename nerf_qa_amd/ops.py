@@ -156,6 +156,23 @@ def conv_pool_stats(inp: torch.Tensor, layer: int, packed: torch.Tensor, prec):
     return pooled, sums
 
 
+def conv1_pool_stats(x: torch.Tensor, y: torch.Tensor, packed: torch.Tensor, prec):
+    """Stage 1 + L2-pool + tap-1 statistics in ONE kernel from the raw frames (include/nqa.h, nqa_conv1_pool_stats):
+    x, y (B,3,H,W) float32 -> (pooled relu1_2 (2B, ceil(H/2), ceil(W/2), 64) f16 NHWC, x images first; sums float64 (B, 64, 5))."""
+    p = prec_id(prec)
+    dev = _need_cuda(x, y, packed)
+    x, y = _f32c(x), _f32c(y)
+    b, c, h, w = x.shape
+    assert c == 3 and y.shape == x.shape
+    pooled = torch.empty((2 * b, (h + 1) // 2, (w + 1) // 2, 64), dtype=torch.float16, device=dev)
+    sums = torch.empty((b, 64, 5), dtype=torch.float64, device=dev)
+    nbytes = lib().nqa_conv_pool_workspace_bytes(b, h, w, 1)
+    ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
+    _call(dev, lib().nqa_conv1_pool_stats, ptr(x), ptr(y), b, h, w, ptr(packed), p, ptr(pooled), ptr(sums), ptr(ws), ws.numel(),
+          stream_ptr(dev))
+    return pooled, sums
+
+
 def nhwc_to_nchw_f32(inp: torch.Tensor, prec) -> torch.Tensor:
     p = prec_id(prec)
     dev = _need_cuda(inp)

@@ -109,3 +109,89 @@ def test_dists_forward_fused_tap_equals_unfused(h, w, b, prec, dev):
     print(f"   tap 2 alone: max|dS1|={t1:.2e} max|dS2|={t2:.2e}")
     assert t1 <= 1e-5 and t2 <= 1e-3, (t1, t2)
     assert torch.equal(s1f[:, :67], s1u[:, :67]) and torch.equal(s2f[:, :67], s2u[:, :67])
+
+
+# stage 1 from the raw frames (nqa_conv1_pool.hip).  (B, H, W): full units, ragged in either direction (a unit is 4 x 32),
+# a second half-strip wholly outside the image (W = 48), one strip pair, many blocks per strip, many pairs
+S1_SHAPES = [(1, 4, 32), (1, 8, 64), (2, 16, 48), (1, 5, 32), (1, 4, 33), (3, 13, 37), (1, 128, 128), (2, 64, 80),
+             (5, 24, 32), (1, 1080, 1920), (1, 269, 477), (16, 32, 32), (1, 16, 16), (2, 20, 17)]
+
+
+@pytest.mark.parametrize("b,h,w", S1_SHAPES, ids=[f"{b}x{h}x{w}" for b, h, w in S1_SHAPES])
+@pytest.mark.parametrize("rounded", [True, False], ids=["rounded_tap", "shipped"])
+def test_fused_stage1_pool_stats_against_the_unfused_operators(b, h, w, rounded, dev, blobs):
+    """rounded_tap (nqa_set_conv_variant + 256): the fused kernel takes relu1_2 rounded to f16 -- the unfused kernels'
+    values -- so the pooled map and the sums must agree as tightly as tap 2's; shipped: unrounded accumulators, agreement
+    to the f16 rounding of the tap (one unit in the last place of a pooled half, 2^-10 of a second moment)."""
+    from nerf_qa_amd import ops
+    g = torch.Generator(device=dev).manual_seed(h * 977 + w + b)
+    x = torch.rand(b, 3, h, w, device=dev, generator=g)
+    y = (0.5 * x + 0.5 * torch.rand(b, 3, h, w, device=dev, generator=g)).clamp_(0, 1)
+    x[:, :, : h // 2, : w // 3] = 1.0  # a constant region: exactly dead / constant channels
+    try:
+        ops.set_conv_variant(ops.DEFAULT_CONV_VARIANT + (256 if rounded else 0))
+        pooled, sums = ops.conv1_pool_stats(x, y, blobs["f16"], "f16")
+    finally:
+        ops.set_conv_variant(ops.DEFAULT_CONV_VARIANT)
+    tap = ops.conv1_fused(torch.cat([x, y]), blobs["f16"], "f16")  # conv1_regw_kernel: relu1_2 as f16 NHWC
+    ref_pool = ops.l2pool(tap, "f16")
+    assert pooled.shape == ref_pool.shape == (2 * b, (h + 1) // 2, (w + 1) // 2, 64)
+    d = (pooled.float() - ref_pool.float()).abs()
+    ulp = torch.maximum(ref_pool.float().abs(), torch.tensor(6.1e-5, device=dev)) * 2.0 ** -10
+    # The fused kernel starts its accumulators at the bias (the unfused one adds it behind the sum) and normalises the
+    # pixels with a corrected reciprocal: a pre-activation within rounding of zero may land on the other side of the
+    # ReLU, so a few pooled values in 10^4 differ by more than the last place -- everything else to one (two) units.
+    over = d > (1.0 if rounded else 2.0) * ulp
+    assert float(over.float().mean()) < 1e-3, (b, h, w, float(over.float().mean()))
+    assert (d <= 0.1 * ref_pool.float().abs() + 2e-3).all(), (b, h, w, float(d.max()))
+    if rounded:
+        assert float((d > 0).float().mean()) < 2e-2
+    t = tap.double()
+    tx, ty = t[:b], t[b:]
+    want = torch.stack([tx.sum((1, 2)), ty.sum((1, 2)), (tx * tx).sum((1, 2)), (ty * ty).sum((1, 2)), (tx * ty).sum((1, 2))], -1)
+    npx = h * w
+    m2 = torch.maximum((want[..., 2] + want[..., 3]) / npx, torch.tensor(1e-12, device=dev, dtype=torch.float64))
+
+    def moments(s):
+        mx, my = s[..., 0] / npx, s[..., 1] / npx
+        return mx, my, s[..., 2] / npx - mx * mx, s[..., 3] / npx - my * my, s[..., 4] / npx - mx * my
+    wm, gm = moments(want), moments(sums)
+    scale = torch.maximum(wm[2] + wm[3], torch.tensor(1e-12, device=dev, dtype=torch.float64))
+    for k in range(5):
+        err = (gm[k] - wm[k]).abs()
+        if rounded:
+            # (a lane's float32 sums run over up to ~2 000 samples of a 1080p run before they are folded in float64:
+            # eps * sqrt(n) of drift on the shifted first moment, i.e. a few 1e-6 of the mean, far inside what S1 / S2 see)
+            tol = 3e-5 * wm[k].abs() + 1e-6 if k < 2 else 1e-4 * scale + 1e-9  # (floors: a ReLU flip in a nearly dead channel)
+        else:  # the tap's f16 rounding: 2^-11 per value, averaging down with the pixel count; bounded loosely
+            tol = 1e-3 * (wm[k].abs() + 1e-3) if k < 2 else 2e-3 * m2 + 1e-12
+        assert (err <= tol).all(), (k, float((err / tol).max()))
+    assert torch.isfinite(sums).all()
+
+
+@pytest.mark.parametrize("h,w,b", [(64, 96, 2), (97, 131, 2), (256, 256, 4), (270, 480, 2), (540, 960, 1)])
+def test_dists_forward_fused_stage1_equals_unfused(h, w, b, dev):
+    """DISTS f16 forward with stage 1 fused (shipped) against the forward with both fused taps off: scores to the f16
+    mode's own rounding noise; with the rounded-tap form of the fused stage 1 as tightly as tap 2's test."""
+    from nerf_qa_amd import ops
+    from nerf_qa_amd.DISTS_pytorch import DISTS
+    m = DISTS(precision="f16", vgg16_path="synth:1234").to(dev).eval()
+    g = torch.Generator(device=dev).manual_seed(h + w)
+    x = torch.rand(b, 3, h, w, device=dev, generator=g)
+    y = (x + 0.1 * torch.randn(x.shape, device=dev, generator=g)).clamp_(0, 1)
+    out = {}
+    try:
+        with torch.no_grad():
+            for name, v in (("fused", 0), ("fused_rounded", 256), ("unfused", 64 + 128)):
+                ops.set_conv_variant(ops.DEFAULT_CONV_VARIANT + v)
+                out[name] = (m(x, y), *m._similarities(x, y))
+    finally:
+        ops.set_conv_variant(ops.DEFAULT_CONV_VARIANT)
+    for name in ("fused", "fused_rounded"):
+        es = (out[name][0] - out["unfused"][0]).abs().max().item()
+        t1 = (out[name][1][:, 3:67] - out["unfused"][1][:, 3:67]).abs().max().item()
+        t2 = (out[name][2][:, 3:67] - out["unfused"][2][:, 3:67]).abs().max().item()
+        print(f"\n{h}x{w} B={b} {name} vs unfused: max|dscore|={es:.2e}; tap 1 alone max|dS1|={t1:.2e} max|dS2|={t2:.2e}")
+        assert es <= 2e-5, (name, es)
+        assert t1 <= (1e-5 if name == "fused_rounded" else 1e-3) and t2 <= (1e-3 if name == "fused_rounded" else 5e-2), (name, t1, t2)
+    assert torch.equal(out["fused"][1][:, :3], out["unfused"][1][:, :3])  # tap 0 (the raw image) is untouched

@@ -68,8 +68,9 @@ def test_dists_b32_256_vs_reference(gain, dev):
     assert x.shape[0] == 32
     # THE GATE: the shipped default ("auto") within 1e-4 of the reference on every pinned weight set.  auto calibrates
     # every rung of its ladder against f32s once per frame-size class with the weights at hand (DISTS_pt.py header;
-    # 256x256 frames: 384 pairs of 256x256 / 320x448): gain 1.0 runs in plain f16 (3.5e-5 with a noise-shaped tail),
-    # gain 1.3 in f32m2 (heavy-tailed: f32m at 2.7e-5 is above the 2e-5 admitted whatever the tail), gain 1.6 in f32s.
+    # 256x256 frames: 384 pairs of 256x256 / 320x448, three of every eight NeRF-render-like since round 4).  On that
+    # content every 16-bit rung shows an outlier of 7.6-8.9e-5 at gain 1.0 (more at 1.3 / 1.6), so all three pinned
+    # sets run f32s at this size (round 3, on textures only: f16 / f32m2 / f32s).
     m = DISTS(vgg16_path=_spec(gain)).to(dev).eval()
     assert m.precision == "auto"
     rep = m.calibrate(dev, 256, 256)
@@ -80,8 +81,8 @@ def test_dists_b32_256_vs_reference(gain, dev):
     print(f"\nDISTS B=32 256x256 gain {gain} DEFAULT (auto -> {rep['choice']}; calibration |f16-f32s| max "
           f"{rep['max_abs_diff']:.2e} rms {rep['rms_diff']:.2e}): max|dscore|={err:.2e}")
     assert err <= 1e-4, ("auto", rep, gain, err)
-    assert rep["choice"] == {1.0: "f16", 1.3: "f32m2", 1.6: "f32s"}[gain], rep  # (what the pinned sets are known to measure)
-    assert m.precision_for(128, 128, dev) == {1.0: "f16w", 1.3: "f32s", 1.6: "f32s"}[gain]  # smaller frames: a stricter class
+    assert rep["choice"] == "f32s", rep  # (what the pinned sets are known to measure: profiles/r04_cal_classes.txt)
+    assert m.precision_for(128, 128, dev) == "f32s"
     assert m.precision_for(100, 120, dev) == "f32s"  # below 128 x 128 pixels: always
     del m
     # per-channel S1 / S2 are quotients with c = 1e-6: on nearly dead channels (variance ~1e-6) a 1e-9 difference in
