@@ -218,8 +218,8 @@ size_t nqa_conv_pool_workspace_bytes(int B, int H, int W, int layer);
 /* The same for the WHOLE of stage 1 (nqa_conv1_pool.hip; DISTS_pt.py:92-94 normalisation + conv1_1 + conv1_2, the L2pooling
  * in front of stage 2 and tap relu1_2's sums) from the raw frames: x, y dev float32 NCHW (B,3,H,W); pooled: dev NHWC f16
  * (2B, ceil(H/2), ceil(W/2), 64), x images first; sums: dev double (B, 64, 5); workspace nqa_conv_pool_workspace_bytes(B, H,
- * W, 1).  NQA_PREC_F16 only so far (NQA_E_SHAPE otherwise).  The sums and the pool take relu1_2 as the fp32 accumulator
- * holds it (nqa_set_conv_variant + 256: rounded to f16 first, as the unfused kernels see it). */
+ * W, 1).  NQA_PREC_F16 only so far (NQA_E_SHAPE otherwise).  The sums and the pool take relu1_2 rounded to f16, the values
+ * the unfused kernels store and read back. */
 int nqa_conv1_pool_stats(const float *x, const float *y, int B, int H, int W, const void *packed, int prec, void *pooled,
                          double *sums, void *ws, size_t ws_bytes, void *stream);
 int nqa_conv_pool_stats(const void *in, int B, int H, int W, int layer, const void *packed, int prec, void *pooled,
@@ -234,7 +234,6 @@ int nqa_conv_pool_stats(const void *in, int B, int H, int W, int layer, const vo
  * adding 32 the implicit GEMM for conv2_2 / conv3_1; adding 64 runs the DISTS path's tap 2 UNFUSED (conv2_2, then the
  * pool + statistics pass over the tap it wrote) instead of conv + L2-pool + statistics in one kernel (nqa_conv_pool.hip);
  * adding 128 does the same for stage 1 (conv1_regw_kernel + pool_stats_kernel instead of nqa_conv1_pool.hip's kernel);
- * adding 256 makes the fused stage 1 round relu1_2 to f16 before its sums and pool (what the unfused kernels see; tests);
  * adding 8 selects the first form of the A-DISTS window pass (every wave loads its own taps instead of sharing them
  * through LDS).  Results agree in every variant to the rounding of a different summation order inside a layer (the
  * tile variants are bit-identical); this only exists so they can be timed against each other in one process.

@@ -399,7 +399,7 @@ int nqa_version(void) { return NQA_VERSION; }
 const char *nqa_last_error(void) { return g_err; }
 
 int nqa_set_conv_variant(int variant) {
-  if (variant < 0 || variant > 511 || (variant & 3) == 3) {
+  if (variant < 0 || variant > 255 || (variant & 3) == 3) {
     set_error("set_conv_variant: unknown variant %d", variant);
     return NQA_E_ARG;
   }
@@ -407,7 +407,7 @@ int nqa_set_conv_variant(int variant) {
   set_adists_window_legacy((variant & 8) != 0);
   set_conv_first_forms((variant >> 4) & 3);
   set_fuse_taps((variant & 64) ? 0 : 1);
-  set_fuse_stage1(((variant & 128) ? 0 : 1) | ((variant & 256) ? 2 : 0));
+  set_fuse_stage1((variant & 128) ? 0 : 1);
   return NQA_OK;
 }
 

@@ -18,6 +18,7 @@
 //   * halo image: [image][6 x 34 pixels] records of 160 bytes (64 channels as two 32-channel chunks + 32 B pad): a
 //     ds_read_b128 of 16 consecutive pixels is bank-conflict-free at that pitch, every tap an immediate offset.
 #include <atomic>
+#include <type_traits>
 
 #include "nqa_common.h"
 
@@ -39,35 +40,51 @@ struct S1Geom {
   static constexpr int RAWP = 40, RAW_ROWS = TH + 5, RAW_IMG = RAW_ROWS * RAWP * 8, RAW_BYTES = 2 * RAW_IMG;  // (+1 row read with zero weights)
   static constexpr int RAW_PX = (TH + 4) * (TW + 4);                         // 288 raw pixels per image
   static constexpr int STG_SLOTS = 12 * 64;                                  // staging: 3 rounds x 4 waves x 64 lanes per plane
-  // DUMP: where the conv1_1 slices of groups that do not exist write (lane * 8 + up to 104 bytes of tile offset)
+  // DUMP: where conv1_1 groups that do not exist write (lane * 8 + up to 104 bytes of tile offset)
   static constexpr int RAW_OFF = 2 * SLOT, STG_OFF = RAW_OFF + 2 * RAW_BYTES, DUMP_OFF = STG_OFF + 3 * STG_SLOTS * 4;
+  // XB: a pass's relu1_2 tile on its way from the wave that computed it to the wave that pools and sums it lives in the
+  // 32-byte PADS of the halo records (never touched by conv1_1's writes or conv1_2's reads): lane (wave w, l) owns the pad
+  // of record 64 w + l of halo slot `pass & 1` -- two buffers at no LDS cost, so ONE barrier per pass hands a tile over
+  static constexpr int XB_PAD = 128;
   static constexpr int LDS = DUMP_OFF + 1024;
   static_assert(LDS <= 163840, "LDS budget");
 };
 
-// ROUND: the sums and the pool take relu1_2 ROUNDED to f16, exactly the values the unfused path stores and reads back (the
-// tests' comparison form, nqa_set_conv_variant + 256); the shipped form skips the two conversions per value.
-template <bool RAGGED, bool ROUND>
-__global__ __launch_bounds__(256, 1) void conv1_pool_kernel(const float *__restrict__ x, const float *__restrict__ y, int B,
-                                                            const char *__restrict__ w1m, const float *__restrict__ bias1,
-                                                            const char *__restrict__ wreg, const float *__restrict__ bias2,
-                                                            char *__restrict__ pooled, float *__restrict__ seam,
-                                                            double *__restrict__ part, int H, int W, int spairs, int rows,
-                                                            int total_units, int part_nblk) {
+// Eight waves, two per SIMD, in TWO ROLES (round 4, second form).  The first form ran everything in four waves, one per
+// SIMD, with the epilogue and conv1_1 cut into slices between the MFMAs: correct, but a single wave issues one instruction
+// per ~4 cycles whatever its kind, and at five vector / LDS / scalar instructions per MFMA the matrix pipe sat idle 63 %
+// of the time (rocprofv3: profiles/r04_pmc_stage1_fused_vs_unfused.txt).  Now
+//   * waves 0..3 (`conv`): conv1_2 only -- 72 MFMAs and 36 fragment reads per pass, the pass's 16 accumulators per lane
+//     through ReLU to packed halves and into the exchange buffer XB;
+//   * waves 4..7 (`tail`, wave w + 4 shares a SIMD with wave w): everything else for the SAME (channel group, half-strip)
+//     -- the previous pass's tile from XB through the statistics, the pool and the stores, conv1_1 of the next unit into
+//     the other halo image, the raw pixels;
+// so the SIMD's arbiter interleaves one wave's MFMAs with the other's vector instructions by itself.  ONE barrier per
+// pass hands a tile over: XB is double-buffered (in the pads of the halo records).
+template <bool RAGGED>
+__global__ __launch_bounds__(512) void conv1_pool_kernel(const float *__restrict__ x, const float *__restrict__ y, int B,
+                                                         const char *__restrict__ w1m, const float *__restrict__ bias1,
+                                                         const char *__restrict__ wreg, const float *__restrict__ bias2,
+                                                         char *__restrict__ pooled, float *__restrict__ seam,
+                                                         double *__restrict__ part, int H, int W, int spairs, int rows,
+                                                         int total_units, int part_nblk) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  typedef _Float16 T;
   typedef S1Geom G;
   typedef __attribute__((ext_vector_type(4))) _Float16 h4;
-  constexpr int PF = 3, GPP = 2, NKS = 18, NI = 2, NP = 8, COUT = 64;
-  constexpr int NST = 8;  // stores per wave and pooled row
+  typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+  typedef __attribute__((ext_vector_type(2))) float f2;
+  constexpr int GPP = 2, NKS = 18, NI = 2, NP = 8, COUT = 64;
+  constexpr int NST = 8;  // stores per tail wave and pooled row
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool tail = wave >= 4;           // (wave-uniform)
+  const int w4 = wave & 3;
   const int l15 = lane & 15, c4 = lane >> 4;
-  const int cg = wave & 1, hs = wave >> 1;  // channel group (32 channels), half-strip (16 columns)
+  const int cg = w4 & 1, hs = w4 >> 1;   // channel group (32 channels), half-strip (16 columns)
   const int HW = H * W;
   const int Ho = (H + 1) >> 1, Wo = (W + 1) >> 1;
-  const int strips = (W + 15) >> 4;  // 16-column strips (the seam planes' index)
+  const int strips = (W + 15) >> 4;      // 16-column strips (the seam planes' index)
 
   // ---- this block's run of units, in [pair][strip pair][row] order (see nqa_conv_pool.hip) ----
   const int nblk = gridDim.x;
@@ -81,11 +98,11 @@ __global__ __launch_bounds__(256, 1) void conv1_pool_kernel(const float *__restr
   const bool warm0 = (u_lo % rows) != 0;  // the run starts inside a strip: one warm-up unit (the tile above), outputs dropped
   const int nsteps = (u_hi - u_lo) + (warm0 ? 1 : 0);
   // unit coordinates of steps s, s + 1, s + 2 (pair, strip pair, row), advanced by one unit per step: the divisions
-  // happen once here, not in every pass (a scalar division is ~50 instructions of a wave that has the SIMD to itself)
+  // happen once here (a scalar division is ~50 instructions)
   struct UC {
     int n, sp, ty;
   };
-  UC uc[3];
+  UC uc[3], ucp;  // ucp: the previous step's (whose last row the tail completes first)
   {
     int u = u_lo - (warm0 ? 1 : 0);
     uc[0].ty = u % rows;
@@ -106,44 +123,95 @@ __global__ __launch_bounds__(256, 1) void conv1_pool_kernel(const float *__restr
   };
   uc[1] = next_uc(uc[0]);
   uc[2] = next_uc(uc[1]);
+  ucp = uc[0];
+  char *const xb = smem + (w4 * 64 + lane) * G::PITCH + G::XB_PAD;  // this lane's 32 bytes of exchange buffer 0 (+ SLOT: buffer 1)
 
-  // ---- weights in registers: conv1_2 (2 tiles x 18 k-steps), conv1_1 (4 tiles x 2 MFMAs), both biases ----
-  u32x4 wf[2][NKS];
+  if (!tail) {
+    // =============================== conv waves: conv1_2, nothing else ===============================
+    u32x4 wf[2][NKS];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks)
-      wf[i][ks] = *reinterpret_cast<const u32x4 *>(wreg + ((((size_t)cg * 2 + i) * NKS + ks) * 64 + lane) * 16);
-  // the weight fragments belong in the ACCUMULATION half of the register file (an MFMA reads its A operand from there
-  // directly): left to itself the allocator kept part of them in VGPRs and copied others in with v_accvgpr_read before use
+      for (int ks = 0; ks < NKS; ++ks)
+        wf[i][ks] = *reinterpret_cast<const u32x4 *>(wreg + ((((size_t)cg * 2 + i) * NKS + ks) * 64 + lane) * 16);
+    f32x4 bia[NI];  // the bias is the accumulators' initial value
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i) bia[i] = *reinterpret_cast<const f32x4 *>(bias2 + cg * 32 + i * 16 + 4 * c4);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): retired with a wait the compiler can see (nqa_conv.hip, 4.2a)
+    asm volatile("s_barrier" ::: "memory");  // P1: raw patches zeroed
+    asm volatile("s_barrier" ::: "memory");  // P2: raw patches of steps 0, 1 committed
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // P3: halo image of step 0 complete
+    for (int step = 0; step < nsteps; ++step) {
+      const int slot_off = (step & 1) * G::SLOT;
+#pragma unroll 1
+      for (int pass = 0; pass < 4; ++pass) {
+        int rb = slot_off + (pass * G::HWD + hs * 16 + l15) * G::PITCH + (c4 << 4);
+        asm volatile("" : "+v"(rb));
+        f32x4 acc[2][GPP];
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+a"(wf[i][ks]));
-  // conv1_1's 8 fragments and its bias (the accumulators' initial value): registers of the accumulation half too.  (Read
-  // from LDS inside the slices, each fragment was waited for in place -- `ds_read; s_waitcnt lgkmcnt(0); v_mfma` eight
-  // times per pass with no other wave on the SIMD to cover the latency: the first build of this kernel ran at half speed.)
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int g = 0; g < GPP; ++g) acc[i][g] = bia[i];
+        u32x4 bf[2][GPP];
+        auto load_b = [&](int ks, u32x4(&b)[GPP]) {
+          const int cc = ks / 9, t = ks - cc * 9, ky = t / 3, kx = t - ky * 3;
+#pragma unroll
+          for (int g = 0; g < GPP; ++g)
+            b[g] = *reinterpret_cast<const u32x4 *>(smem + rb + (g * G::IMG_BYTES + (ky * G::HWD + kx) * G::PITCH + cc * 64));
+        };
+        load_b(0, bf[0]);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+          if (ks + 1 < NKS) load_b(ks + 1, bf[(ks + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);
+#ifndef NQA_S1_NO_MFMA  // (timing-only ablations, tools/gpu_s1_ablate.sh: results are wrong on purpose)
+#pragma unroll
+          for (int g = 0; g < GPP; ++g)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+              acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wf[i][ks]),
+                                                                 __builtin_bit_cast(f16x8, bf[ks & 1][g]), acc[i][g], 0, 0, 0);
+#else
+          if (ks == 0)
+#pragma unroll
+            for (int g = 0; g < GPP; ++g) asm volatile("" ::"v"(bf[0][g]), "v"(bf[1][g]));
+#endif
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // ReLU on packed halves; piece i = (tile i: image 0 channels e, image 1 channels e)
+        const h2 z = {(_Float16)0.f, (_Float16)0.f};
+        u32x4 piece[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int g = 0; g < GPP; ++g) {
+            const h2 lo = __builtin_elementwise_max(__builtin_convertvector((f2){acc[i][g][0], acc[i][g][1]}, h2), z);
+            const h2 hi = __builtin_elementwise_max(__builtin_convertvector((f2){acc[i][g][2], acc[i][g][3]}, h2), z);
+            piece[i][2 * g] = __builtin_bit_cast(unsigned, lo);
+            piece[i][2 * g + 1] = __builtin_bit_cast(unsigned, hi);
+          }
+        // buffer pass & 1: its previous content (the tile of pass - 2) was read by the tail waves before the last barrier
+        *reinterpret_cast<u32x4 *>(xb + (pass & 1) * G::SLOT) = piece[0];
+        *reinterpret_cast<u32x4 *>(xb + (pass & 1) * G::SLOT + 16) = piece[1];
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // this pass's tile is in XB
+      }
+    }
+    return;
+  }
+
+  // =============================== tail waves ===============================
+  // conv1_1's 8 fragments and its bias (the accumulators' initial value)
   u32x4 w1f[4][2];
   f32x4 b1v[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      w1f[i][m] = *reinterpret_cast<const u32x4 *>(w1m + ((i * 2 + m) * 64 + lane) * 16);
-      asm volatile("" : "+a"(w1f[i][m]));
-    }
+    for (int m = 0; m < 2; ++m) w1f[i][m] = *reinterpret_cast<const u32x4 *>(w1m + ((i * 2 + m) * 64 + lane) * 16);
     b1v[i] = *reinterpret_cast<const f32x4 *>(bias1 + 16 * i + 4 * c4);
-    asm volatile("" : "+a"(b1v[i]));
   }
-  // conv1_2's bias is the accumulators' initial value (no add in the epilogue, no zeroing move in front of a pass)
-  f32x4 bia[NI];
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    bia[i] = *reinterpret_cast<const f32x4 *>(bias2 + cg * 32 + i * 16 + 4 * c4);
-    asm volatile("" : "+a"(bia[i]));
-  }
+  const int ttid = tid - 256;  // 0..255 among the tail waves
   // zero both raw patches (their borders and the spare row are read with zero weights or as padding)
-  for (int i = tid; i < 2 * G::RAW_BYTES / 8; i += 256) reinterpret_cast<u32x2 *>(smem + G::RAW_OFF)[i] = (u32x2){0u, 0u};
+  for (int i = ttid; i < 2 * G::RAW_BYTES / 8; i += 256) reinterpret_cast<u32x2 *>(smem + G::RAW_OFF)[i] = (u32x2){0u, 0u};
 
   // ---- raw pixels: 2 images x 8 x 36 per unit; chunk c = round * 4 + wave holds 64 pixels of ONE image (5 chunks per
   // image, 288 of their 320 slots live), so a DMA instruction has one image = one buffer resource ----
@@ -155,13 +223,13 @@ __global__ __launch_bounds__(256, 1) void conv1_pool_kernel(const float *__restr
   bool r_live[3], r_ok[3] = {false, false, false};
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
-    const int c = r * 4 + wave, p = (c % 5) * 64 + lane;
+    const int c = r * 4 + w4, p = (c % 5) * 64 + lane;
     r_img[r] = c / 5;
     r_live[r] = c < 10 && p < G::RAW_PX;
     r_row[r] = p / (G::TW + 4);
     r_col[r] = p - r_row[r] * (G::TW + 4);  // (once per kernel)
   }
-  auto raw_fetch = [&](const UC &c, bool real) {  // (every wave issues its 9 pieces whatever: the counted waits rely on it)
+  auto raw_fetch = [&](const UC &c, bool real) {  // (every tail wave issues its 9 pieces whatever: the counted waits rely on it)
     const int n = real ? c.n : 0;
     const int x0 = c.sp * G::TW, y0 = c.ty * G::TH;
 #pragma unroll
@@ -173,9 +241,9 @@ __global__ __launch_bounds__(256, 1) void conv1_pool_kernel(const float *__restr
           __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(img), 0, 3u * (unsigned)HW * 4u, 0x00020000);
       const unsigned off = r_ok[r] ? (unsigned)((gy * W + gx) * 4) : kOOB;
 #pragma unroll
-      for (int c = 0; c < 3; ++c)
+      for (int c3 = 0; c3 < 3; ++c3)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
-            rsrc, (lds_void_q *)(smem + G::STG_OFF + (c * G::STG_SLOTS + (r * 4 + wave) * 64) * 4), 4, off, c * HW * 4, 0, 0);
+            rsrc, (lds_void_q *)(smem + G::STG_OFF + (c3 * G::STG_SLOTS + (r * 4 + w4) * 64) * 4), 4, off, c3 * HW * 4, 0, 0);
     }
   };
   auto raw_commit = [&](int buf) {  // staging -> normalised f16 raw patch `buf` (the caller has waited for the DMA)
@@ -184,12 +252,11 @@ __global__ __launch_bounds__(256, 1) void conv1_pool_kernel(const float *__restr
       if (r_live[r]) {
         h4 v;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const float raw = *reinterpret_cast<const float *>(smem + G::STG_OFF + (c * G::STG_SLOTS + (r * 4 + wave) * 64 + lane) * 4);
-          // (x - mean) / std as a multiplication by 1 / std with one residual correction: the quotient the division gives,
-          // in 4 instructions instead of its ~10
-          const float d = raw - mean[c], q0 = d * isd[c], q1 = fmaf(fmaf(-q0, sd[c], d), isd[c], q0);
-          v[c] = (_Float16)(r_ok[r] ? q1 : 0.f);
+        for (int c3 = 0; c3 < 3; ++c3) {
+          const float raw = *reinterpret_cast<const float *>(smem + G::STG_OFF + (c3 * G::STG_SLOTS + (r * 4 + w4) * 64 + lane) * 4);
+          // (x - mean) / std as a multiplication by 1 / std with one residual correction: 4 instructions instead of ~10
+          const float d = raw - mean[c3], q0 = d * isd[c3], q1 = fmaf(fmaf(-q0, sd[c3], d), isd[c3], q0);
+          v[c3] = (_Float16)(r_ok[r] ? q1 : 0.f);
         }
         v[3] = (_Float16)0.f;
         *reinterpret_cast<h4 *>(smem + G::RAW_OFF + buf * G::RAW_BYTES + r_img[r] * G::RAW_IMG +
@@ -198,14 +265,8 @@ __global__ __launch_bounds__(256, 1) void conv1_pool_kernel(const float *__restr
     }
   };
 
-  // ---- conv1_1 of one group of 16 halo pixels, in three pieces (they ride in the k loops as slices) ----
-  // group gi = wave + 4 j (j = 0..6; 26 groups): image gi / 13, halo pixels (gi % 13) * 16 + l15 of its 204
-  f32x4 a1[4];
-  u32x4 bfr[2];
-  int c_q = 0, c_dst = G::DUMP_OFF;  // the group's halo pixel of this lane; LDS byte address of its record (or the dump)
-  bool c_inside = false;
-  unsigned c_mask = 0u;             // all ones where the group's pixel of this lane lies inside the image
-  // the unit whose halo image is being produced (set per unit, outside the k loops: no branch inside them)
+  // ---- conv1_1 of one group of 16 halo pixels -> the halo image of the unit `c11_*` describe ----
+  // group gi = w4 + 4 j (j = 0..6; 26 groups): image gi / 13, halo pixels (gi % 13) * 16 + l15 of its 204
   int c11_y0 = 0, c11_x0 = 0, c11_par = 0;
   bool c11_real = false;
   auto c11_set = [&](const UC &c, bool real, int step) {
@@ -214,62 +275,68 @@ __global__ __launch_bounds__(256, 1) void conv1_pool_kernel(const float *__restr
     c11_x0 = c.sp * G::TW;
     c11_par = step & 1;
   };
-  auto c11_load = [&](int j) {
-    // (full-rate integer arithmetic only: 24-bit multiplies and a multiply-shift division -- the 32-bit multiplies and
-    // the 64-bit address arithmetic of the first build ran at a quarter of the rate, ~100 cycles per group)
-    const int gi = wave + 4 * j;
-    const int img = gi >= G::NGI ? 1 : 0, q = (gi - img * G::NGI) * 16 + l15, qc = q < G::NQI ? q : G::NQI - 1;
-    const int hy = (int)(__umul24((unsigned)qc, 1928u) >> 16);  // qc / 34 for qc < 512
-    const int hx = qc - (int)__umul24((unsigned)hy, (unsigned)G::HWD);
-    const int gy = c11_y0 - 1 + hy, gx = c11_x0 - 1 + hx;
-    c_inside = ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
-    c_mask = c_inside ? 0xFFFFFFFFu : 0u;
-    const bool live = c11_real & (gi < G::NGRP) & (q < G::NQI);
-    c_dst = live ? c11_par * G::SLOT + img * G::IMG_BYTES + (int)__umul24((unsigned)q, (unsigned)G::PITCH) + (c4 << 3)
-                 : G::DUMP_OFF + lane * 8;
-    c_q = q;
-    const unsigned rawb = (unsigned)(G::RAW_OFF + c11_par * G::RAW_BYTES + img * G::RAW_IMG + (c4 & 1) * 16) +
-                          (__umul24((unsigned)(hy + (c4 >> 1)), (unsigned)G::RAWP) + (unsigned)hx) * 8u;
+  // NG groups at once (j0, j0 + 1, ...): their read -> 8 MFMAs -> convert -> write chains interleave, which is all the
+  // latency hiding a wave gets whose SIMD partner is busy with conv1_2
+  // what a group's lane needs is fixed for the kernel's life but for the unit's origin and parity: per group j the byte
+  // offset of its raw fragment (parity 0), of its halo record (parity 0; negative: the group / pixel does not exist),
+  // and its halo row / column -- 21 registers instead of ~25 address instructions per group and unit
+  int t_raw[7], t_dst[7], t_yx[7];
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      const char *rp = smem + rawb + m * (2 * G::RAWP * 8);
-      const u32x2 lo = *reinterpret_cast<const u32x2 *>(rp), hi = *reinterpret_cast<const u32x2 *>(rp + 8);
-      bfr[m] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+  for (int j = 0; j < 7; ++j) {
+    const int gi = w4 + 4 * j;
+    const int img = gi >= G::NGI ? 1 : 0, q = (gi - img * G::NGI) * 16 + l15, qc = q < G::NQI ? q : G::NQI - 1;
+    const int hy = qc / G::HWD, hx = qc - hy * G::HWD;
+    t_yx[j] = (hy << 8) | hx;
+    t_raw[j] = G::RAW_OFF + img * G::RAW_IMG + (c4 & 1) * 16 + ((hy + (c4 >> 1)) * G::RAWP + hx) * 8;
+    t_dst[j] = (gi < G::NGRP && q < G::NQI) ? img * G::IMG_BYTES + q * G::PITCH + (c4 << 3) : -1;
+  }
+  auto c11_groups = [&](int j0, auto ng_tag) {  // (j0 is a compile-time constant at every call)
+    constexpr int NG = decltype(ng_tag)::value;
+    int dst[NG];
+    unsigned mask[NG];
+    u32x4 bfr[NG][2];
+    f32x4 a1[NG][4];
+#pragma unroll
+    for (int u = 0; u < NG; ++u) {
+      const int j = j0 + u;
+      const int gy = c11_y0 - 1 + (t_yx[j] >> 8), gx = c11_x0 - 1 + (t_yx[j] & 255);
+      const bool inside = ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
+      mask[u] = inside ? 0xFFFFFFFFu : 0u;
+      dst[u] = (c11_real & (t_dst[j] >= 0)) ? c11_par * G::SLOT + t_dst[j] : G::DUMP_OFF + lane * 8;
+      const unsigned rawb = (unsigned)(t_raw[j] + c11_par * G::RAW_BYTES);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const char *rp = smem + rawb + m * (2 * G::RAWP * 8);
+        const u32x2 lo = *reinterpret_cast<const u32x2 *>(rp), hi = *reinterpret_cast<const u32x2 *>(rp + 8);
+        bfr[u][m] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+      }
     }
-  };
-  // channel tile i, MFMA m: kernel rows 0-1 (m = 0, the accumulator starts at the bias), then row 2 + zeros (m = 1)
-  auto c11_mma = [&](int i, int m) {
-    if (m == 0)
-      a1[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w1f[i][0]), __builtin_bit_cast(f16x8, bfr[0]), b1v[i], 0, 0, 0);
-    else
-      a1[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w1f[i][1]), __builtin_bit_cast(f16x8, bfr[1]), a1[i], 0, 0, 0);
-  };
-  // ReLU and the zero outside the image (conv1_2's padding) on PACKED halves: convert two at a time, v_pk_max_f16 against 0,
-  // AND with the lane's all-ones / all-zeros mask -- 6 vector instructions per tile instead of 14
-  typedef __attribute__((ext_vector_type(2))) _Float16 h2;
-  typedef __attribute__((ext_vector_type(2))) float f2;
-  auto c11_store = [&](int i) {  // channels 16 i + 4 c4 ..: chunk i >> 1, quarter 2 (i & 1) + (c4 >> 1), half (c4 & 1)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)  // kernel rows 0-1 (the accumulator starts at the bias) ...
+#pragma unroll
+      for (int u = 0; u < NG; ++u)
+        a1[u][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w1f[i][0]), __builtin_bit_cast(f16x8, bfr[u][0]), b1v[i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)  // ... then row 2 (+ zeros)
+#pragma unroll
+      for (int u = 0; u < NG; ++u)
+        a1[u][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w1f[i][1]), __builtin_bit_cast(f16x8, bfr[u][1]), a1[u][i], 0, 0, 0);
+    // ReLU and the zero outside the image (conv1_2's padding) on packed halves
     const h2 z = {(_Float16)0.f, (_Float16)0.f};
-    const h2 lo = __builtin_elementwise_max(__builtin_convertvector((f2){a1[i][0], a1[i][1]}, h2), z);
-    const h2 hi = __builtin_elementwise_max(__builtin_convertvector((f2){a1[i][2], a1[i][3]}, h2), z);
-    const u32x2 v = {__builtin_bit_cast(unsigned, lo) & c_mask, __builtin_bit_cast(unsigned, hi) & c_mask};
-    *reinterpret_cast<u32x2 *>(smem + c_dst + (i >> 1) * 64 + (i & 1) * 32) = v;
+#pragma unroll
+    for (int u = 0; u < NG; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {  // channels 16 i + 4 c4 ..: chunk i >> 1, quarter 2 (i & 1) + (c4 >> 1), half (c4 & 1)
+        const h2 lo = __builtin_elementwise_max(__builtin_convertvector((f2){a1[u][i][0], a1[u][i][1]}, h2), z);
+        const h2 hi = __builtin_elementwise_max(__builtin_convertvector((f2){a1[u][i][2], a1[u][i][3]}, h2), z);
+        const u32x2 vv = {__builtin_bit_cast(unsigned, lo) & mask[u], __builtin_bit_cast(unsigned, hi) & mask[u]};
+        *reinterpret_cast<u32x2 *>(smem + dst[u] + (i >> 1) * 64 + (i & 1) * 32) = vv;
+      }
   };
-  auto c11_slice = [&](int pass, int ks) {
-    const int j = pass * 2 + (ks >= 9 ? 1 : 0), t = ks % 9;  // (slot 7 is idle: its groups do not exist and land in the dump)
-    if (t == 0) c11_load(j);
-    if (t >= 1 && t <= 4) {  // two tiles per slice, the dependent second MFMA of a tile two slices behind its first
-      const int m = (t - 1) >> 1, i0 = 2 * ((t - 1) & 1);
-      c11_mma(i0, m);
-      c11_mma(i0 + 1, m);
-    }
-    if (t >= 5) {
-      c11_store(t - 5);
-    }
-  };
+  typedef std::integral_constant<int, 2> Two;
+  typedef std::integral_constant<int, 1> One;
 
-  // ---- per-lane state of the fused epilogue (nqa_conv_pool.hip) ----
-  f32x4 accs[2][2][GPP];  // [pass parity][tile][image]: a pass accumulates into one set while the other set's epilogue runs
+  // ---- per-lane state: vertical pool sums, shifted statistics (nqa_conv_pool.hip) ----
   float U[NI][GPP][4];
   float piv[NP], s1x[NP], s1y[NP], s2x[NP], s2y[NP], sxy[NP], n_lane = 0.f;
 #pragma unroll
@@ -280,12 +347,6 @@ __global__ __launch_bounds__(256, 1) void conv1_pool_kernel(const float *__restr
       for (int e = 0; e < 4; ++e) U[i][g][e] = 0.f;
 #pragma unroll
   for (int p = 0; p < NP; ++p) piv[p] = s1x[p] = s1y[p] = s2x[p] = s2y[p] = sxy[p] = 0.f;
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int g = 0; g < GPP; ++g) accs[1][i][g] = (f32x4){0.f, 0.f, 0.f, 0.f};  // (the phantom epilogue of the first pass reads it)
-  float c_vmask = 1.f;
-  unsigned c_po_lane = kOOB, c_so_lane = kOOB;
   const bool is15 = l15 == 15, is0 = l15 == 0, even_in = (l15 & 1) == 0 && l15 != 0;
   const size_t nimg = 2 * (size_t)B;
   const unsigned pooled_bytes = (unsigned)(nimg * Ho * Wo * COUT * 2);            // (host-checked < 2^31)
@@ -296,111 +357,110 @@ __global__ __launch_bounds__(256, 1) void conv1_pool_kernel(const float *__restr
   const unsigned y_seam_off = (unsigned)((size_t)B * strips * Ho * COUT);
   const int ch_lane0 = cg * 32 + 4 * c4;
 
-  float rx = 0.f, ry = 0.f;
-  h4 outh[GPP];
-  f32x4 seamv[GPP];
-  // (the sums and the pool take relu1_2 as the accumulator holds it, NOT rounded to the f16 the unfused path stores the tap
-  // in: two conversions per value less in a kernel bound by its vector instructions, and closer to the reference)
-  auto pair_values = [&](int p, int par) {  // par: parity of the pass whose accumulators these are
-    const int i = p >> 2, e = p & 3;
-    rx = fmaxf(accs[par][i][0][e], 0.f);
-    ry = fmaxf(accs[par][i][1][e], 0.f);
-    if constexpr (ROUND) {
-      rx = (float)(_Float16)rx;
-      ry = (float)(_Float16)ry;
-    }
-  };
-  auto pair_stats = [&](int p) {
-    float dx = rx - piv[p], dy = ry - piv[p];
-    if constexpr (RAGGED) {
-      dx *= c_vmask;
-      dy *= c_vmask;
-    }
-    s1x[p] += dx;
-    s1y[p] += dy;
-    s2x[p] = fmaf(dx, dx, s2x[p]);
-    s2y[p] = fmaf(dy, dy, s2y[p]);
-    sxy[p] = fmaf(dx, dy, sxy[p]);
-  };
-  auto complete = [&](int i, int g, int e, float s) {
-    const float u = U[i][g][e] + s;
-    const float a = u + dpp1_row_shr1(u);
-    const float pv = a + dpp1_row_shl1(a);
-    seamv[g][e] = is15 ? u : pv;
-    float val = __builtin_amdgcn_sqrtf(fmaf(pv, 0.0625f, 1e-12f));
-    asm volatile("" : "+v"(val));
-    outh[g][e] = (_Float16)val;
-    U[i][g][e] = s;  // the next window's row -1 (zeroed again between the k loops where a new strip starts)
-  };
-  auto emit_tile = [&](int i) {
+  // the tile of one pass out of XB: v[i][g][e] as floats (the tap's f16 values)
+  float v[NI][GPP][4];
+  auto take_tile = [&](int buf) {
+    // (an LDS-address-space VOLATILE read: the pieces are written by other waves between two barriers.  Through the generic
+    // pointer hipcc re-read only the first dword of each piece inside the unit loop and carried the other three over from
+    // the previous pass; a volatile generic access turns into flat loads, which the counted vmcnt waits cannot live with.)
+    typedef __attribute__((address_space(3))) const volatile u32x4 lds_cv4;
+    u32x4 pc[NI];
 #pragma unroll
-    for (int g = 0; g < GPP; ++g) {
-      const unsigned po = c_po_lane + (g ? y_pool_off : 0u) + (unsigned)(i * 16) * 2u;
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, outh[g]), prsrc, po, 0, 0);
-      const unsigned so = c_so_lane + (g ? y_seam_off * 4u : 0u) + (unsigned)(i * 16) * 4u;
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, seamv[g]), srsrc, so, 0, 0);
-    }
+    for (int i = 0; i < NI; ++i) pc[i] = *reinterpret_cast<lds_cv4 *>((lds_void_q *)(xb + buf * G::SLOT + i * 16));
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int g = 0; g < GPP; ++g) {
+        const h2 lo = __builtin_bit_cast(h2, (uint32_t)pc[i][2 * g]), hi = __builtin_bit_cast(h2, (uint32_t)pc[i][2 * g + 1]);
+        v[i][g][0] = (float)lo[0];
+        v[i][g][1] = (float)lo[1];
+        v[i][g][2] = (float)hi[0];
+        v[i][g][3] = (float)hi[1];
+      }
   };
-  // 18 k-steps carry 32 epilogue slices: two per k-step for the first 16
-  auto epi_even_slice = [&](int sl) {
-    const int p = sl >> 2, sub = sl & 3, i = p >> 2, e = p & 3;
-    if (sub == 0) {
-      pair_values(p, 0);
-      if (p == 0) n_lane += RAGGED ? c_vmask : 1.f;
-      asm volatile("" : "+v"(rx), "+v"(ry));
-    }
-    if (sub == 1) {
-      pair_stats(p);
-      asm volatile("" : "+v"(s1x[p]), "+v"(s1y[p]), "+v"(s2x[p]), "+v"(s2y[p]), "+v"(sxy[p]));
-    }
-    if (sub == 2) {
-      const float mx = RAGGED ? rx * c_vmask : rx, my = RAGGED ? ry * c_vmask : ry;
-      U[i][0][e] = fmaf(2.f * mx, mx, U[i][0][e]);
-      U[i][1][e] = fmaf(2.f * my, my, U[i][1][e]);
-      asm volatile("" : "+v"(U[i][0][e]), "+v"(U[i][1][e]));
-    }
-  };
-  auto epi_odd_slice = [&](int sl) {
-    const int p = sl >> 2, sub = sl & 3, i = p >> 2, e = p & 3;
-    if (sub == 0) {
-      pair_values(p, 1);
-      if (p == 0) n_lane += RAGGED ? c_vmask : 1.f;
-      asm volatile("" : "+v"(rx), "+v"(ry));
-    }
-    if (sub == 1) {
-      pair_stats(p);
-      asm volatile("" : "+v"(s1x[p]), "+v"(s1y[p]), "+v"(s2x[p]), "+v"(s2y[p]), "+v"(sxy[p]));
-    }
-    if (sub == 2) {
-      const float mx = RAGGED ? rx * c_vmask : rx;
-      complete(i, 0, e, mx * mx);
-      asm volatile("" : "+v"(U[i][0][e]), "+v"(seamv[0][e]));
-    }
-    if (sub == 3) {
-      const float my = RAGGED ? ry * c_vmask : ry;
-      complete(i, 1, e, my * my);
-      asm volatile("" : "+v"(U[i][1][e]), "+v"(seamv[1][e]));
-      if (e == 3) emit_tile(i);
-    }
-  };
-  auto epi_even = [&](int ks) {
-    if (ks < 16) {
-      epi_even_slice(2 * ks);
-      epi_even_slice(2 * ks + 1);
-    }
-  };
-  auto epi_odd = [&](int ks) {
-    if (ks < 16) {
-      epi_odd_slice(2 * ks);
-      epi_odd_slice(2 * ks + 1);
-    }
-  };
-
-  auto reset_stats = [&]() {
+  auto stats_tile = [&](float vmask) {
+    n_lane += RAGGED ? vmask : 1.f;
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       const int i = p >> 2, e = p & 3;
-      piv[p] = fmaxf(accs[0][i][0][e], 0.f);  // (pass 0 of the step has just been computed)
+      float dx = v[i][0][e] - piv[p], dy = v[i][1][e] - piv[p];
+      if constexpr (RAGGED) {
+        dx *= vmask;
+        dy *= vmask;
+      }
+      s1x[p] += dx;
+      s1y[p] += dy;
+      s2x[p] = fmaf(dx, dx, s2x[p]);
+      s2y[p] = fmaf(dy, dy, s2y[p]);
+      sxy[p] = fmaf(dx, dy, sxy[p]);
+    }
+  };
+  // even rows (0, 2): U = (row above) + 2 s
+  auto pool_even = [&](float vmask) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int g = 0; g < GPP; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float m = RAGGED ? v[i][g][e] * vmask : v[i][g][e];
+          U[i][g][e] = fmaf(2.f * m, m, U[i][g][e]);
+        }
+  };
+  // odd rows (1, 3): U += s completes pooled row (row - 1) / 2: horizontal taps by DPP, root, stores; U = s carries on
+  auto pool_odd = [&](float vmask, unsigned po_lane, unsigned so_lane) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      h4 outh[GPP];
+      f32x4 seamv[GPP];
+#pragma unroll
+      for (int g = 0; g < GPP; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float m = RAGGED ? v[i][g][e] * vmask : v[i][g][e];
+          const float sq = m * m;
+          const float u = U[i][g][e] + sq;
+          const float a = u + dpp1_row_shr1(u);
+          const float pv = a + dpp1_row_shl1(a);
+          seamv[g][e] = is15 ? u : pv;
+          outh[g][e] = (_Float16)__builtin_amdgcn_sqrtf(fmaf(pv, 0.0625f, 1e-12f));
+          U[i][g][e] = sq;
+        }
+#pragma unroll
+      for (int g = 0; g < GPP; ++g) {
+        // (an out-of-range offset stays out of range under the small additions: every tail wave issues the same stores)
+        const unsigned po = po_lane + (g ? y_pool_off : 0u) + (unsigned)(i * 16) * 2u;
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, outh[g]), prsrc, po, 0, 0);
+        const unsigned so = so_lane + (g ? y_seam_off * 4u : 0u) + (unsigned)(i * 16) * 4u;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, seamv[g]), srsrc, so, 0, 0);
+      }
+    }
+  };
+  // where pooled row oy = y0 / 2 + j of unit `c` goes, for this lane (kOOB: nowhere)
+  // (lane constants: this lane's part of the pooled / seam byte offsets; kOOB where the lane never stores)
+  const unsigned lane_po = even_in ? (unsigned)(((l15 >> 1) * COUT + ch_lane0) * 2) : kOOB;
+  const unsigned lane_so0 = is0 ? (unsigned)ch_lane0 * 4u : kOOB;
+  const unsigned lane_so15 = is15 ? (seam_plane + (unsigned)(Ho * COUT) + (unsigned)ch_lane0) * 4u : kOOB;
+  auto pool_offsets = [&](const UC &c, int j, bool emit, unsigned &po_lane, unsigned &so_lane) {
+    const int s16 = c.sp * 2 + hs, x0 = s16 * 16, oy = ((c.ty * G::TH) >> 1) + j, ox0 = x0 >> 1;
+    const bool live = emit && oy < Ho && x0 < W;  // (block-uniform)
+    const unsigned pool_row = (((unsigned)c.n * (unsigned)Ho + (unsigned)oy) * (unsigned)Wo + (unsigned)ox0) * (COUT * 2u);
+    const unsigned seam_row = (((unsigned)c.n * (unsigned)strips + (unsigned)s16) * (unsigned)Ho + (unsigned)oy) * (COUT * 4u);
+    const bool right = s16 + 1 < strips;
+    // (kOOB + a row offset below 2^31 stays out of range)
+    po_lane = live ? lane_po + pool_row : kOOB;
+    if constexpr (RAGGED) po_lane = (ox0 + (l15 >> 1) < Wo) ? po_lane : kOOB;
+    so_lane = live ? (right ? (is15 ? lane_so15 : lane_so0) : lane_so0) + seam_row : kOOB;
+  };
+  auto row_mask = [&](const UC &c, int pass) -> float {
+    if constexpr (!RAGGED) return 1.f;
+    const int x0 = (c.sp * 2 + hs) * 16, y0 = c.ty * G::TH;
+    return (y0 + pass < H && x0 + l15 < W) ? 1.f : 0.f;
+  };
+  auto reset_stats = [&]() {  // (v holds row 0 of the pair's first tile: the pivots)
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      piv[p] = v[p >> 2][0][p & 3];
       s1x[p] = s1y[p] = s2x[p] = s2y[p] = sxy[p] = 0.f;
     }
     n_lane = 0.f;
@@ -413,154 +473,133 @@ __global__ __launch_bounds__(256, 1) void conv1_pool_kernel(const float *__restr
       double r[5] = {ax + nn * pv, ay + nn * pv, (double)s2x[p] + 2.0 * pv * ax + nn * pv * pv,
                      (double)s2y[p] + 2.0 * pv * ay + nn * pv * pv, (double)sxy[p] + pv * ax + pv * ay + nn * pv * pv};
 #pragma unroll
-      for (int s = 0; s < 5; ++s) {
+      for (int s5 = 0; s5 < 5; ++s5) {
 #pragma unroll
-        for (int m = 8; m >= 1; m >>= 1) r[s] += __shfl_xor(r[s], m, 16);
+        for (int m = 8; m >= 1; m >>= 1) r[s5] += __shfl_xor(r[s5], m, 16);
       }
       // the two half-strip waves of a channel group hold sums of the same channels: rows 2 * block + hs of the partials
       if (l15 == 0) {
         const int c = ch_lane0 + i * 16 + e;
         double *dst = part + (((size_t)n * part_nblk + 2 * blockIdx.x + hs) * COUT + c) * 5;
 #pragma unroll
-        for (int s = 0; s < 5; ++s) dst[s] = r[s];
+        for (int s5 = 0; s5 < 5; ++s5) dst[s5] = r[s5];
       }
-    }
-  };
-
-  // ---- the k loop of one pass: conv1_2 of one tile row (x | y), the previous pass's epilogue and a piece of the next
-  // unit's conv1_1 riding along ----
-  int slot_off = 0;
-  auto kloop = [&](int pass, auto epi) {
-    int rb = slot_off + (pass * G::HWD + hs * 16 + l15) * G::PITCH + (c4 << 4);
-    asm volatile("" : "+v"(rb));
-    f32x4(&acc)[2][GPP] = accs[pass & 1];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int g = 0; g < GPP; ++g) acc[i][g] = bia[i];
-    u32x4 bf[PF + 1][GPP];
-    auto load_b = [&](int ks, u32x4(&b)[GPP]) {
-      const int cc = ks / 9, t = ks - cc * 9, ky = t / 3, kx = t - ky * 3;
-#pragma unroll
-      for (int g = 0; g < GPP; ++g)
-        b[g] = *reinterpret_cast<const u32x4 *>(smem + rb + (g * G::IMG_BYTES + (ky * G::HWD + kx) * G::PITCH + cc * 64));
-    };
-#pragma unroll
-    for (int ks = 0; ks < PF; ++ks) load_b(ks, bf[ks]);
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-      if (ks + PF < NKS) load_b(ks + PF, bf[(ks + PF) % (PF + 1)]);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int g = 0; g < GPP; ++g)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-          acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wf[i][ks]),
-                                                             __builtin_bit_cast(f16x8, bf[ks % (PF + 1)][g]), acc[i][g], 0, 0, 0);
-#ifndef NQA_S1_NO_EPI  // (timing-only ablations, tools/gpu_s1_ablate.sh: results are wrong on purpose)
-      epi(ks);
-#endif
-#ifndef NQA_S1_NO_C11
-      c11_slice(pass, ks);
-#endif
-#pragma unroll
-      for (int m = 0; m < 6; ++m) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-  auto set_ctx = [&](const UC &c, const UC &cn, bool has_next, int pass, bool emit) {
-    const int n = c.n, sp = c.sp, ty = c.ty;
-    const int s16 = sp * 2 + hs, x0 = s16 * 16, y0 = ty * G::TH;
-    if constexpr (RAGGED) c_vmask = (y0 + pass < H && x0 + l15 < W) ? 1.f : 0.f;
-    if (pass & 1) {
-      const int oy = (y0 >> 1) + (pass >> 1), ox0 = x0 >> 1;
-      const bool live = emit && oy < Ho && x0 < W;
-      const unsigned pool_row = (((unsigned)n * (unsigned)Ho + (unsigned)oy) * (unsigned)Wo + (unsigned)ox0) * (COUT * 2u);
-      const unsigned seam_row = (((unsigned)n * (unsigned)strips + (unsigned)s16) * (unsigned)Ho + (unsigned)oy) * COUT;
-      const bool right = s16 + 1 < strips;
-      const bool mine = live & even_in & (!RAGGED | (ox0 + (l15 >> 1) < Wo));
-      const bool seam_l = live & (is0 | (is15 & right));
-      c_po_lane = mine ? pool_row + (unsigned)(((l15 >> 1) * COUT + ch_lane0) * 2) : kOOB;
-      c_so_lane = seam_l ? (seam_row + (is15 ? seam_plane + (unsigned)(Ho * COUT) : 0u) + (unsigned)ch_lane0) * 4u : kOOB;
-      (void)cn;
-      (void)has_next;
     }
   };
 
   // ---- prologue: raw patches of steps 0 and 1, the halo image of step 0 ----
-  __syncthreads();  // the zeroed raw patches
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // P1
   raw_fetch(uc[0], true);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   raw_commit(0);
   raw_fetch(uc[1], 1 < nsteps);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   raw_commit(1);
-  __syncthreads();
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // P2
   c11_set(uc[0], true, 0);
-#pragma unroll 1
-  for (int j = 0; j < 7; ++j) {
-    c11_load(j);
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) c11_mma(i, m);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) c11_store(i);
-  }
+  c11_groups(0, Two());
+  c11_groups(2, Two());
+  c11_groups(4, Two());
+  c11_groups(6, One());
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // P3
 
   int flush_n = -1;
+  bool have_prev = false;  // XB holds a real tile (from the second pass on)
   for (int step = 0; step < nsteps; ++step) {
     const int n = uc[0].n;
     const bool warm = warm0 && step == 0;
-    // halo image `step` (written during the previous unit) and raw patch step + 1 (committed at its end) become visible;
-    // halo image / raw patch of the other parity are free
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    raw_fetch(uc[2], step + 2 < nsteps);  // lands under this unit's MFMAs
-    slot_off = (step & 1) * G::SLOT;
-    c11_set(uc[1], step + 1 < nsteps, step + 1);
     const bool fresh = step == (warm0 ? 1 : 0);
     const bool change = !fresh && !warm && n != flush_n;
+    bool flushed = false;
+    raw_fetch(uc[2], step + 2 < nsteps);  // lands while this unit is computed
+    c11_set(uc[1], step + 1 < nsteps, step + 1);
 #pragma unroll
-    for (int pp = 0; pp < 2; ++pp) {  // (unrolled: the pass number, and with it every conv1_1 group index, is static)
-      kloop(2 * pp, epi_odd);
-      set_ctx(uc[0], uc[1], step + 1 < nsteps, 2 * pp, !warm);
-      if (pp == 0) {
-        // the previous step's last row is now in U as this tile's row -1: wrong where this tile starts a strip (image top)
-        if (uc[0].ty == 0) {
+    for (int pass = 0; pass < 4; ++pass) {  // (unrolled: static group indices, row parities and branches)
+      // the tile of the PREVIOUS pass (pass 0: the previous step's row 3) is in XB since the last barrier
+#ifdef NQA_S1_NO_EPI
+      if (false) {
+#else
+      if (have_prev) {
+#endif
+        take_tile((pass + 1) & 1);
+        const UC &tc = pass == 0 ? ucp : uc[0];
+        const int tp = (pass + 3) & 3;                      // that tile's row in its unit
+        const bool temit = pass == 0 ? !(warm0 && step == 1) : !warm;
+        if (pass == 1) {
+          // row 0 of this step: where a strip starts the carried row above is the zero padding; where a pair starts
+          // (or the run does) the lane sums change hands
+          if (uc[0].ty == 0) {
 #pragma unroll
-          for (int i = 0; i < NI; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
-            for (int g = 0; g < GPP; ++g)
+              for (int g = 0; g < GPP; ++g)
 #pragma unroll
-              for (int e = 0; e < 4; ++e) U[i][g][e] = 0.f;
-        }
-        if (fresh || change) {
-          if (change) flush_stats(flush_n);
-          if (!warm) {
-            reset_stats();
-            flush_n = n;
+                for (int e = 0; e < 4; ++e) U[i][g][e] = 0.f;
+          }
+          if (fresh || change) {
+            if (change) {
+              flush_stats(flush_n);
+              flushed = true;
+            }
+            if (!warm) {
+              reset_stats();
+              flush_n = n;
+            }
           }
         }
+        const float vm = row_mask(tc, tp);
+        stats_tile(vm);
+        if (tp & 1) {
+          unsigned po_lane, so_lane;
+          pool_offsets(tc, tp >> 1, temit, po_lane, so_lane);
+          pool_odd(vm, po_lane, so_lane);
+        } else {
+          pool_even(vm);
+        }
+      } else if (pass == 1) {  // (a run's very first tile: nothing carried, nothing to hand over)
+        take_tile(0);
+        if (!warm) {
+          reset_stats();
+          flush_n = n;
+        }
+        stats_tile(row_mask(uc[0], 0));
+        pool_even(row_mask(uc[0], 0));
       }
-      kloop(2 * pp + 1, epi_even);
-      set_ctx(uc[0], uc[1], step + 1 < nsteps, 2 * pp + 1, !warm);
+      if (pass >= 1) have_prev = true;
+      // conv1_1 of the next unit: two groups per pass (one in the last)
+#ifndef NQA_S1_NO_C11
+      if (pass == 0) c11_groups(0, Two());
+      if (pass == 1) c11_groups(2, Two());
+      if (pass == 2) c11_groups(4, Two());
+      if (pass == 3) c11_groups(6, One());
+#endif
+      if (pass == 3) {
+        // the raw pixels of step + 2 were requested at the start of this unit; the only younger operations of this wave
+        // are the unit's 2 * NST stores (and, rarely, a flush's): retire the pixels without waiting for the stores
+        if (flushed)
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (step == 0)  // (the run's first unit issued one pooled row's stores, not two)
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NST) : "memory");
+        raw_commit(step & 1);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // this pass's LDS writes are out; the conv waves' new tile is in XB
     }
-    // the raw pixels of step + 2 were requested a whole unit ago; the only younger operations are this unit's 2 * NST
-    // stores (and, rarely, a flush's): retire the pixels without waiting for the stores
-    if (change)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NST) : "memory");
-    raw_commit(step & 1);
+    ucp = uc[0];
     uc[0] = uc[1];
     uc[1] = uc[2];
     uc[2] = next_uc(uc[2]);
   }
-#pragma unroll
-  for (int sl = 0; sl < 32; ++sl) epi_odd_slice(sl);
+  // ---- drain: the last unit's row 3, then this wave's last sums ----
+  {
+    take_tile(1);
+    const float vm = row_mask(ucp, 3);
+    stats_tile(vm);
+    unsigned po_lane, so_lane;
+    pool_offsets(ucp, 1, !(warm0 && nsteps == 1), po_lane, so_lane);
+    pool_odd(vm, po_lane, so_lane);
+  }
   if (flush_n >= 0) flush_stats(flush_n);
 #endif
 }
@@ -582,8 +621,7 @@ static int s1_num_cus() {
 }
 
 static thread_local int g_fuse_stage1 = 1;  // nqa_set_conv_variant bit 7 (128): 0 = the unfused stage 1 + pool + statistics
-static thread_local int g_round_tap1 = 0;   // bit 8 (256): the fused stage 1 rounds relu1_2 to f16 before its sums and pool (tests)
-void set_fuse_stage1(int on) { g_fuse_stage1 = on & 1; g_round_tap1 = (on >> 1) & 1; }
+void set_fuse_stage1(int on) { g_fuse_stage1 = on & 1; }
 
 bool conv1_pool_fusable(int B, int H, int W, int blob_prec) {
   if (!g_fuse_stage1 || blob_prec != NQA_PREC_F16 || W < 16 || H < 4) return false;
@@ -594,7 +632,7 @@ bool conv1_pool_fusable(int B, int H, int W, int blob_prec) {
   return true;
 }
 
-template <bool RAGGED, bool ROUND>
+template <bool RAGGED>
 static int launch_conv1_pool(const float *x, const float *y, int B, int H, int W, const char *packed, void *pooled, float *seam,
                              double *part, hipStream_t st) {
   typedef S1Geom G;
@@ -603,7 +641,7 @@ static int launch_conv1_pool(const float *x, const float *y, int B, int H, int W
   (void)hipGetDevice(&dev);
   std::atomic<bool> &attr_done = attr_done_dev[dev & 63];
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv1_pool_kernel<RAGGED, ROUND>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv1_pool_kernel<RAGGED>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             G::LDS) != hipSuccess) {
       set_error("conv1_pool: cannot raise the dynamic LDS limit to %d bytes", G::LDS);
       return NQA_E_LAUNCH;
@@ -627,7 +665,7 @@ static int launch_conv1_pool(const float *x, const float *y, int B, int H, int W
   const float *b2 = reinterpret_cast<const float *>(packed + layer_bias_offset(1, NQA_PREC_F16));
   {
     TimedLaunch t(NQA_K_CONV, st);
-    conv1_pool_kernel<RAGGED, ROUND><<<grid, 256, G::LDS, st>>>(x, y, B, packed + layer0_m16_offset(NQA_PREC_F16), b1,
+    conv1_pool_kernel<RAGGED><<<grid, 512, G::LDS, st>>>(x, y, B, packed + layer0_m16_offset(NQA_PREC_F16), b1,
                                                          packed + regw_offset(1, NQA_PREC_F16), b2, static_cast<char *>(pooled),
                                                          seam, part, H, W, spairs, rows, (int)units, NQA_FUSED_PART_BLOCKS_S1);
     const int rc = check_launch("conv1_pool");
@@ -641,11 +679,8 @@ int conv1_pool_stats_fused(const float *x, const float *y, int B, int H, int W, 
                            double *part, hipStream_t st) {
   const char *p = static_cast<const char *>(packed);
   const bool ragged = (H % 4) != 0 || (W % 32) != 0;  // (a unit is 32 columns: its second half-strip may lie outside the image)
-  if (g_round_tap1)
-    return ragged ? launch_conv1_pool<true, true>(x, y, B, H, W, p, pooled, seam, part, st)
-                  : launch_conv1_pool<false, true>(x, y, B, H, W, p, pooled, seam, part, st);
-  return ragged ? launch_conv1_pool<true, false>(x, y, B, H, W, p, pooled, seam, part, st)
-                : launch_conv1_pool<false, false>(x, y, B, H, W, p, pooled, seam, part, st);
+  return ragged ? launch_conv1_pool<true>(x, y, B, H, W, p, pooled, seam, part, st)
+                : launch_conv1_pool<false>(x, y, B, H, W, p, pooled, seam, part, st);
 }
 
 }  // namespace nqa

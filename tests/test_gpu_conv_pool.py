@@ -118,21 +118,16 @@ S1_SHAPES = [(1, 4, 32), (1, 8, 64), (2, 16, 48), (1, 5, 32), (1, 4, 33), (3, 13
 
 
 @pytest.mark.parametrize("b,h,w", S1_SHAPES, ids=[f"{b}x{h}x{w}" for b, h, w in S1_SHAPES])
-@pytest.mark.parametrize("rounded", [True, False], ids=["rounded_tap", "shipped"])
-def test_fused_stage1_pool_stats_against_the_unfused_operators(b, h, w, rounded, dev, blobs):
-    """rounded_tap (nqa_set_conv_variant + 256): the fused kernel takes relu1_2 rounded to f16 -- the unfused kernels'
-    values -- so the pooled map and the sums must agree as tightly as tap 2's; shipped: unrounded accumulators, agreement
-    to the f16 rounding of the tap (one unit in the last place of a pooled half, 2^-10 of a second moment)."""
+def test_fused_stage1_pool_stats_against_the_unfused_operators(b, h, w, dev, blobs):
+    """The fused kernel's tail waves take relu1_2 rounded to f16 -- the unfused kernels' values -- so the pooled map and
+    the sums agree as tightly as tap 2's, but for the few pre-activations that sit within rounding of zero (below)."""
+    rounded = True
     from nerf_qa_amd import ops
     g = torch.Generator(device=dev).manual_seed(h * 977 + w + b)
     x = torch.rand(b, 3, h, w, device=dev, generator=g)
     y = (0.5 * x + 0.5 * torch.rand(b, 3, h, w, device=dev, generator=g)).clamp_(0, 1)
     x[:, :, : h // 2, : w // 3] = 1.0  # a constant region: exactly dead / constant channels
-    try:
-        ops.set_conv_variant(ops.DEFAULT_CONV_VARIANT + (256 if rounded else 0))
-        pooled, sums = ops.conv1_pool_stats(x, y, blobs["f16"], "f16")
-    finally:
-        ops.set_conv_variant(ops.DEFAULT_CONV_VARIANT)
+    pooled, sums = ops.conv1_pool_stats(x, y, blobs["f16"], "f16")
     tap = ops.conv1_fused(torch.cat([x, y]), blobs["f16"], "f16")  # conv1_regw_kernel: relu1_2 as f16 NHWC
     ref_pool = ops.l2pool(tap, "f16")
     assert pooled.shape == ref_pool.shape == (2 * b, (h + 1) // 2, (w + 1) // 2, 64)
@@ -182,16 +177,16 @@ def test_dists_forward_fused_stage1_equals_unfused(h, w, b, dev):
     out = {}
     try:
         with torch.no_grad():
-            for name, v in (("fused", 0), ("fused_rounded", 256), ("unfused", 64 + 128)):
+            for name, v in (("fused", 0), ("unfused", 64 + 128)):
                 ops.set_conv_variant(ops.DEFAULT_CONV_VARIANT + v)
                 out[name] = (m(x, y), *m._similarities(x, y))
     finally:
         ops.set_conv_variant(ops.DEFAULT_CONV_VARIANT)
-    for name in ("fused", "fused_rounded"):
+    for name in ("fused",):
         es = (out[name][0] - out["unfused"][0]).abs().max().item()
         t1 = (out[name][1][:, 3:67] - out["unfused"][1][:, 3:67]).abs().max().item()
         t2 = (out[name][2][:, 3:67] - out["unfused"][2][:, 3:67]).abs().max().item()
         print(f"\n{h}x{w} B={b} {name} vs unfused: max|dscore|={es:.2e}; tap 1 alone max|dS1|={t1:.2e} max|dS2|={t2:.2e}")
         assert es <= 2e-5, (name, es)
-        assert t1 <= (1e-5 if name == "fused_rounded" else 1e-3) and t2 <= (1e-3 if name == "fused_rounded" else 5e-2), (name, t1, t2)
+        assert t1 <= 1e-5 and t2 <= 1e-3, (name, t1, t2)
     assert torch.equal(out["fused"][1][:, :3], out["unfused"][1][:, :3])  # tap 0 (the raw image) is untouched

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Timing-only ablations of the fused stage-1 kernel (nqa_conv1_pool.hip) on the GPU box: the shipped library against
-# builds without the epilogue slices, without the conv1_1 slices, and without both (results of those are wrong on
+# builds whose tail waves skip the tile work (statistics, pool, stores), conv1_1, or both, and builds whose conv waves
+# skip their MFMAs (results of those are wrong on
 # purpose); prints the conv class time of a DISTS B=8 1080p step for each.  usage: bash tools/gpu_s1_ablate.sh
 set -e
 cd "$(dirname "$0")/.."
@@ -35,3 +36,5 @@ run shipped
 run no_epi -DNQA_S1_NO_EPI
 run no_c11 -DNQA_S1_NO_C11
 run no_epi_no_c11 -DNQA_S1_NO_EPI -DNQA_S1_NO_C11
+run no_mfma -DNQA_S1_NO_MFMA
+run no_mfma_no_c11 -DNQA_S1_NO_MFMA -DNQA_S1_NO_C11
