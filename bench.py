@@ -80,10 +80,11 @@ COMPANIONS = (("1080p", None, "synth:1234:1.3"), ("1080p", None, "synth:1234:1.6
 PEAK_F16_TFLOPS = 2500.0  # dense f16/bf16 MFMA, MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3   # exact-f32 MFMA
 PEAK_HBM_GBS = 8000.0
+MEASURED_STREAM_GBS = 6200.0  # best 4-read:1-write stream (non-temporal loads), profiles/r04_stream_bw.txt
 MFMA_PER_PRODUCT = {"f16": 1, "bf16": 1, "f32s": 3, "f32": 1}  # f32m: 2 for conv layers 1..6, 3 for 7..12
 MIXED_LAST_2TERM_LAYER = {"f32m": 6, "f32m2": 3, "f32m4": 9, "f16w": 12}
 MIXED_STAGES = {"f32m": 3, "f32m2": 2, "f32m4": 4, "f16w": 5}
-TRAFFIC_FILE = "profiles/r03_traffic.json"
+TRAFFIC_FILE = "profiles/r04_traffic.json"
 AUTO_REPORT = {}  # DISTS' one-time precision calibration (what `auto`, the shipped default, chose and on what evidence)
 
 
@@ -109,12 +110,13 @@ def tap_elem_bytes(prec, k):
     return e, e
 
 
-def pool_bytes_per_image(h, w, prec):
-    """Algorithmic HBM bytes of the pool+statistics pass per image: taps 1..4 read once, a quarter written
-    (SURVEY 8d, L2-pool row), in the element sizes the mode stores them in."""
+def pool_bytes_per_image(h, w, prec, taps=(1, 2, 3, 4)):
+    """Algorithmic HBM bytes of the pool+statistics pass per image: each tap in `taps` read once, a quarter written
+    (SURVEY 8d, L2-pool row), in the element sizes the mode stores them in.  Taps the forward closes inside their
+    conv kernel (ops.dists_fused_taps) never go through this pass and are left out by the caller."""
     dims = ops.pyramid_dims(h, w)
     total = 0
-    for k in range(4):
+    for k in (t - 1 for t in taps):
         hk, wk = dims[k]
         c = ops.CHNS[k + 1]
         ein, eout = tap_elem_bytes(prec, k)
@@ -153,7 +155,7 @@ def traffic_for(traffic, key):
     return t
 
 
-def rooflines(ktimes, h, w, b, prec, traffic):
+def rooflines(ktimes, h, w, b, prec, traffic, fused=None):
     """roofline (MFMA conv stack) and roofline_hbm (pool+statistics) from the HIP-event times of one timed run."""
     ig_flops, _ = conv_flops_per_image(h, w)
     issued_flops, _ = conv_flops_per_image(h, w, prec)
@@ -163,10 +165,11 @@ def rooflines(ktimes, h, w, b, prec, traffic):
     ach = ig_flops * 2 * b * steps / (ms_ig * 1e-3) / 1e12 if ms_ig > 0 else None
     peak = PEAK_F32_TFLOPS if prec == "f32" else PEAK_F16_TFLOPS
     roof = {
-        "kernel": "VGG conv layers 1..12 on MFMA: conv1_regw_kernel (stage 1), conv3x3_regw_kernel / conv3x3_regw128_kernel "
-                  "(conv2_1 / conv2_2, conv3_1), conv3x3_igemm_kernel (the rest; all layers in f32; f32s: conv1_regw_split_kernel "
-                  "for stage 1, igemm behind; f32m: the two-term instances of the first three for layers 1..4, two-term "
-                  "igemm for 5..6, f32s igemm for 7..12)",
+        "kernel": "VGG conv layers 1..12 on MFMA: conv1_pool_kernel (stage 1 + pool + statistics, f16) or conv1_regw_kernel, "
+                  "conv3x3_regw_kernel (conv2_1), conv3x3_regw128_pool_kernel (conv2_2 + pool + statistics, f16 stage) or "
+                  "conv3x3_regw128_kernel (conv2_2, conv3_1), conv3x3_igemm_kernel (the rest; all layers in f32; f32s: "
+                  "conv1_regw_split_kernel for stage 1, igemm behind; f32m: the two-term instances of the first three for "
+                  "layers 1..4, two-term igemm for 5..6, f32s igemm for 7..12)",
         "bound": "mfma", "achieved": round(ach, 2) if ach else None, "peak": peak, "unit": "TFLOP/s",
         "frac": round(ach / peak, 4) if ach else None,
         "traffic": traffic.get("conv"), "traffic_source": traffic.get("_source"),
@@ -183,12 +186,20 @@ def rooflines(ktimes, h, w, b, prec, traffic):
                         "layers 1..6 (activation x weight-hi, x weight-lo) and three behind: `frac` is algorithmic "
                         "FLOP/s over the 2.5 PF f16 peak, `frac_of_issued_mfma` is the matrix cores' load")
     n_p, ms_p = ktimes["l2pool"]
-    ach_b = pool_bytes_per_image(h, w, prec) * 2 * b * steps / (ms_p * 1e-3) / 1e9 if ms_p > 0 and steps else None
-    hbm = {"kernel": "pool_stats_kernel (L2-pool + the five statistics sums of taps 1..4, one pass)", "bound": "hbm",
-           "achieved": round(ach_b, 1) if ach_b else None, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-           "frac": round(ach_b / PEAK_HBM_GBS, 4) if ach_b else None, "traffic": traffic.get("pool"),
-           "traffic_source": traffic.get("_source"), "launches": n_p,
-           "bytes_per_launch_avg": round(pool_bytes_per_image(h, w, prec) * 2 * b / 4)}
+    fused = ops.dists_fused_taps(b, h, w, prec) if fused is None else fused
+    left = tuple(t for t in (1, 2, 3, 4) if t not in fused)
+    pool_b = pool_bytes_per_image(h, w, prec, left)
+    ach_b = pool_b * 2 * b * steps / (ms_p * 1e-3) / 1e9 if ms_p > 0 and steps and left else None
+    hbm = {"kernel": f"pool_stats_kernel (L2-pool + the five statistics sums of taps {list(left)}, one pass each; taps "
+                     f"{list(fused)} are pooled and summed inside their conv kernel and never reach HBM at full resolution)",
+           "bound": "hbm", "achieved": round(ach_b, 1) if ach_b else None, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+           "frac": round(ach_b / PEAK_HBM_GBS, 4) if ach_b else None,
+           "frac_of_measured_stream": round(ach_b / MEASURED_STREAM_GBS, 4) if ach_b else None,
+           "measured_stream_note": f"{MEASURED_STREAM_GBS:.0f} GB/s = the best 4-read:1-write streaming kernel on this "
+                                   "hardware (profiles/r04_stream_bw.txt), the attainable ceiling of this access pattern",
+           "traffic": traffic.get("pool"), "traffic_source": traffic.get("_source"), "launches": n_p,
+           "bytes_per_launch_avg": round(pool_b * 2 * b / max(len(left), 1)),
+           "fused_taps": list(fused), "seam_launches": ktimes.get("pool_seam", (0, 0.0))[0]}
     kms = {k: round(v[1] / max(steps, 1), 4) for k, v in ktimes.items() if v[0]}
     return roof, hbm, kms
 

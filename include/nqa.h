@@ -215,6 +215,12 @@ int nqa_resize_pil_bilinear_u8(const uint8_t *in, int n, int Hin, int Win, int H
  * whose stage 3 stays 16-bit has a fused form so far: anything else returns NQA_E_SHAPE.  nqa_dists_forward takes this
  * path by itself (nqa_set_conv_variant + 64 turns it off); these two entry points exist for tests and tools. */
 size_t nqa_conv_pool_workspace_bytes(int B, int H, int W, int layer);
+
+/* Which tapped maps nqa_dists_forward(B, H, W, prec) closes inside their conv kernel (pool + statistics fused, the
+ * full-resolution map never written): fused[k] = 1 for tap k (1..5; fused[0] is the image, always 0).  Depends on the
+ * shape, the mode and the calling thread's nqa_set_conv_variant bits 64 / 128.  bench.py prices its HBM roofline
+ * (the pool_stats passes that remain) with it. */
+int nqa_dists_fused_taps(int B, int H, int W, int prec, int fused[6]);
 /* The same for the WHOLE of stage 1 (nqa_conv1_pool.hip; DISTS_pt.py:92-94 normalisation + conv1_1 + conv1_2, the L2pooling
  * in front of stage 2 and tap relu1_2's sums) from the raw frames: x, y dev float32 NCHW (B,3,H,W); pooled: dev NHWC f16
  * (2B, ceil(H/2), ceil(W/2), 64), x images first; sums: dev double (B, 64, 5); workspace nqa_conv_pool_workspace_bytes(B, H,
@@ -247,7 +253,8 @@ int nqa_set_conv_variant(int variant);
  * those events and returns, per kernel class, the number of launches and the summed
  * device time in milliseconds, then clears the ring.  Thread-local: only the enabling thread's
  * launches are bracketed, and it collects only its own. */
-enum { NQA_K_CONV1 = 0, NQA_K_CONV = 1, NQA_K_POOL = 2, NQA_K_STATS = 3, NQA_K_ADISTS = 4, NQA_K_PREP = 5, NQA_K_COUNT = 6 };
+enum { NQA_K_CONV1 = 0, NQA_K_CONV = 1, NQA_K_POOL = 2, NQA_K_STATS = 3, NQA_K_ADISTS = 4, NQA_K_PREP = 5, NQA_K_SEAM = 6,
+       NQA_K_COUNT = 7 };  /* NQA_K_CONV holds the fused conv + pool + statistics kernels too; NQA_K_SEAM their seam pass */
 int nqa_timing_enable(int on);
 int nqa_timing_collect(int launches[NQA_K_COUNT], double ms[NQA_K_COUNT]);
 

@@ -48,6 +48,8 @@ from ..vgg_weights import load_vgg16_convs
 # (profiles/r02_stress_final.txt), and tools/gpu_stress.py now re-checks that with both conv1_1 forms.
 DEFAULT_PRECISION = "auto"
 AUTO_EXACT_PIXELS = 128 * 128
+TWO_STREAM_MIN_PAIRS = 4          # batches of this many pairs or more ...
+TWO_STREAM_MIN_PIXELS = 512 * 512  # ... of frames this large run as two half-batches on two HIP streams (_score)
 
 
 class ADISTS(torch.nn.Module):
@@ -73,6 +75,7 @@ class ADISTS(torch.nn.Module):
                              "(see the module docstring); use 'auto' (default), 'f32s', 'f32' or the opt-in 'f16'")
         self._packed = {}
         self._ws = ops.Workspace()
+        self._side = {}
 
     # the window parameters are kept for state_dict compatibility (ADISTS.py:66-69,102-110);
     # the kernel uses the same separable 1-D Gaussian
@@ -107,7 +110,7 @@ class ADISTS(torch.nn.Module):
 
     def __getstate__(self):
         d = self.__dict__.copy()
-        for k in ("_packed", "_ws"):  # device scratch never travels (__setstate__ rebuilds it)
+        for k in ("_packed", "_ws", "_side"):  # device scratch and streams never travel (__setstate__ rebuilds them)
             d.pop(k, None)
         return d
 
@@ -117,7 +120,32 @@ class ADISTS(torch.nn.Module):
         d.setdefault("precision", os.environ.get("NQA_ADISTS_PRECISION", DEFAULT_PRECISION))
         d.setdefault("vgg_source", "unpickled module (Conv2d weights of stage1..5)")
         d.pop("_packed_key", None)
-        d["_packed"], d["_ws"] = {}, ops.Workspace()
+        d["_packed"], d["_ws"], d["_side"] = {}, ops.Workspace(), {}
+
+    def _score(self, x, y, prec):
+        """D (B,) of a batch.  Large frames in batches of TWO_STREAM_MIN_PAIRS or more run as two half-batches on two
+        HIP streams: the VALU-bound window pass of one half rides beside the MFMA-bound conv stack of the other (+2-3 %
+        at 1080p, profiles/r03_adists_two_streams.txt; pairs are independent, so the scores are those of one call).
+        NQA_ADISTS_STREAMS=1 switches it off."""
+        dev, b = x.device, x.shape[0]
+        packed = self._packed_weights(dev, prec)
+        two = (dev.type == "cuda" and b >= TWO_STREAM_MIN_PAIRS and x.shape[-2] * x.shape[-1] >= TWO_STREAM_MIN_PIXELS
+               and os.environ.get("NQA_ADISTS_STREAMS", "2") != "1")
+        if not two:
+            return ops.adists_forward(x, y, packed, prec, self._ws)
+        side = self._side.get(str(dev))
+        if side is None:
+            side = self._side[str(dev)] = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+        main = torch.cuda.current_stream(dev)
+        x, y = x.contiguous(), y.contiguous()  # (so that the halves are views)
+        half, outs = (b + 1) // 2, []
+        for st, (lo, hi) in zip(side, ((0, half), (half, b))):
+            st.wait_stream(main)  # the frames (and the packed weights) were produced on the caller's stream
+            with torch.cuda.stream(st):
+                outs.append(ops.adists_forward(x[lo:hi], y[lo:hi], packed, prec, self._ws))  # (scratch is per stream)
+        for st in side:
+            main.wait_stream(st)
+        return torch.cat(outs)
 
     def forward_once(self, x):
         prec = self.precision_for(x.shape[-2], x.shape[-1])
@@ -137,7 +165,7 @@ class ADISTS(torch.nn.Module):
             _, m = ops.adists_forward(x, y, self._packed_weights(x.device, prec), prec, self._ws, with_map=True)
             b = m.shape[0]
             return m.unsqueeze(1).expand(b, b, *m.shape[1:]).contiguous()
-        d = ops.adists_forward(x, y, self._packed_weights(x.device, prec), prec, self._ws)
+        d = self._score(x, y, prec)
         if as_loss:
             return 1 - d.mean()
         return 1 - d

@@ -27,7 +27,7 @@ def stage_prec(prec: int, stage: int) -> int:
         return prec
     return PREC_F16 if stage < MIXED_STAGES[prec] else PREC_F32S
 NUM_CONVS, NUM_TAPS, TOTAL_CHNS = 13, 6, 1475
-K_NAMES = ("conv1_1", "conv_igemm", "l2pool", "stats", "adists", "prep")
+K_NAMES = ("conv1_1", "conv_igemm", "l2pool", "stats", "adists", "prep", "pool_seam")
 
 _vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
 _SIGNATURES = {
@@ -50,6 +50,7 @@ _SIGNATURES = {
                                   _vp, _sz, _vp, _vp, _vp]),
     "nqa_dists_score": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "nqa_conv_pool_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "nqa_dists_fused_taps": (_i, [_i, _i, _i, _i, C.POINTER(_i)]),
     "nqa_conv_pool_stats": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "nqa_conv1_pool_stats": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "nqa_adists_workspace_bytes": (_sz, [_i, _i, _i, _i]),

@@ -861,6 +861,14 @@ static __global__ void part_reduce_kernel(const double *__restrict__ part, int n
 }
 
 static int fused_part_rows(int layer) { return layer == 1 ? NQA_FUSED_PART_BLOCKS_S1 : NQA_FUSED_PART_BLOCKS; }
+int nqa_dists_fused_taps(int B, int H, int W, int prec, int fused[6]) {
+  if (!fused) return NQA_E_ARG;
+  if (bad_dims("dists_fused_taps", B, H, W, prec, 0, true)) return NQA_E_ARG;
+  bool f[6];
+  dists_fused_taps(B, H, W, prec, f);
+  for (int k = 0; k < 6; ++k) fused[k] = f[k] ? 1 : 0;
+  return NQA_OK;
+}
 size_t nqa_conv_pool_workspace_bytes(int B, int H, int W, int layer) {
   if (B <= 0 || H <= 0 || W <= 0 || layer < 1 || layer >= NQA_NUM_CONVS) return 0;
   const int C = kConvs[layer].cout;

@@ -494,7 +494,7 @@ __global__ __launch_bounds__(256) void pool_seam_kernel(const float *__restrict_
 // the seam pass behind a fused conv + pool kernel (f16 pooled map; also nqa_conv1_pool.hip's)
 int pool_seam_finish(const float *seam, void *pooled, int nimg, int strips, int Ho, int Wo, int C, hipStream_t st) {
   const long total = (long)nimg * strips * Ho * (C / 4);
-  TimedLaunch t(NQA_K_POOL, st);
+  TimedLaunch t(NQA_K_SEAM, st);
   pool_seam_kernel<false><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(seam, static_cast<char *>(pooled), nimg, strips, Ho, Wo, C,
                                                                              total);
   return check_launch("pool_seam");

@@ -184,16 +184,19 @@ def nhwc_to_nchw_f32(inp: torch.Tensor, prec) -> torch.Tensor:
 
 
 class Workspace:
-    """Grow-only device scratch, one per (module, device); avoids allocator traffic per call."""
+    """Grow-only device scratch, one buffer per (module, device, HIP stream): avoids allocator traffic per call, and two
+    streams that run the same module side by side (ADISTS' two half-batches) never share scratch."""
 
     def __init__(self):
-        self.buf = None
+        self.bufs = {}
 
     def get(self, nbytes: int, dev: torch.device) -> torch.Tensor:
-        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != dev:
-            self.buf = None
-            self.buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
-        return self.buf
+        key = (str(dev), torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0)
+        buf = self.bufs.get(key)
+        if buf is None or buf.numel() < nbytes:
+            self.bufs[key] = buf = None  # (released before the larger one is requested)
+            self.bufs[key] = buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
+        return buf
 
 
 def tap_prec(prec, k: int) -> int:
@@ -297,6 +300,14 @@ DEFAULT_CONV_VARIANT = 1  # the library's start-up value (include/nqa.h)
 
 def set_conv_variant(v: int) -> None:
     check(lib().nqa_set_conv_variant(int(v)))
+
+
+def dists_fused_taps(b: int, h: int, w: int, prec) -> tuple:
+    """Taps (1..5) whose L2-pool and statistics nqa_dists_forward runs inside the stage-closing conv kernel for this
+    shape and mode (the calling thread's conv variant bits 64 / 128 switch them off)."""
+    f = (C.c_int * 6)()
+    check(lib().nqa_dists_fused_taps(int(b), int(h), int(w), prec_id(prec), f))
+    return tuple(k for k in range(6) if f[k])
 
 
 def timing_enable(on: bool) -> None:

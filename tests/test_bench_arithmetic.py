@@ -53,3 +53,22 @@ def test_committed_traffic_summary_is_readable():
     shown = b.traffic_for(t, "1080p/f16")
     assert "_source" in shown and (("conv" in shown) == bool(t.get("_lib_matches")))
     assert b.traffic_for(t, "no/such")["_source"].startswith("none")
+
+
+def test_hbm_roofline_prices_only_the_taps_that_still_go_through_pool_stats():
+    b = _bench()
+    from nerf_qa_amd import ops
+    # pure f16 at 1080p: stage 1 and conv2_2 close their taps themselves; two-term stage 1 stays unfused; f32s all unfused
+    assert ops.dists_fused_taps(8, 1080, 1920, "f16") == (1, 2)
+    assert ops.dists_fused_taps(8, 1080, 1920, "f32m") == (2,)
+    assert ops.dists_fused_taps(8, 1080, 1920, "f32s") == ()
+    assert ops.dists_fused_taps(1, 8, 8, "f16") == ()  # (below the fused kernels' smallest tile)
+    full = b.pool_bytes_per_image(1080, 1920, "f16")
+    rest = b.pool_bytes_per_image(1080, 1920, "f16", (3, 4))
+    assert rest < 0.21 * full  # taps 1 and 2 are four fifths of the pass's bytes
+    kt = {"conv1_1": (0, 0.0), "conv_igemm": (24, 34.0), "l2pool": (4, 1.2), "stats": (4, 0.3), "adists": (0, 0.0),
+          "prep": (0, 0.0), "pool_seam": (4, 0.05)}
+    roof, hbm, kms = b.rooflines(kt, 1080, 1920, 8, "f16", {}, fused=(1, 2))
+    assert hbm["fused_taps"] == [1, 2] and hbm["launches"] == 4 and hbm["seam_launches"] == 4
+    assert abs(hbm["achieved"] - rest * 16 * 2 / 1.2e-3 / 1e9) < 1.0 and hbm["bytes_per_launch_avg"] == round(rest * 16 / 2)
+    assert abs(kms["conv_igemm"] - 17.0) < 1e-9 and roof["launches"] == 24

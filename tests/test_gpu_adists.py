@@ -82,3 +82,35 @@ def test_adists_module_surface(dev):
     assert amap.shape == (2, 2, 64, 72) and torch.equal(amap[:, 0], amap[:, 1])
     feats = m.forward_once(x)
     assert [f.shape[1] for f in feats] == [3, 64, 128, 256, 512, 512]
+
+
+def test_adists_two_stream_halves_equal_one_call(dev, monkeypatch):
+    """Batches of >= 4 large frames run as two half-batches on two HIP streams (ADISTS._score): same scores as one
+    call on one stream (pairs are independent; only the statistics' block partition follows the batch size: 1e-7)."""
+    import warnings
+    from nerf_qa_amd.ADISTS import ADISTS
+    import sys
+    A = sys.modules[ADISTS.__module__]  # (the package re-exports the class under the module's own name)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = ADISTS(vgg16_path="synth:1234").to(dev).eval()
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = torch.rand(5, 3, 520, 600, device=dev, generator=g)
+    y = (x + 0.08 * torch.randn(x.shape, device=dev, generator=g)).clamp_(0, 1)
+    assert x.shape[0] >= A.TWO_STREAM_MIN_PAIRS and 520 * 600 >= A.TWO_STREAM_MIN_PIXELS
+    with torch.no_grad():
+        two = m(x, y, as_loss=False)
+        assert len(m._ws.bufs) == 2  # one scratch buffer per side stream
+        again = m(x, y, as_loss=False)
+        monkeypatch.setenv("NQA_ADISTS_STREAMS", "1")
+        one = m(x, y, as_loss=False)
+    assert two.shape == (5,) and torch.equal(two, again)
+    assert (two - one).abs().max().item() <= 3e-7, (two - one).abs().max().item()
+    # a caller's own side stream: the result is ordered behind it
+    st = torch.cuda.Stream(dev)
+    st.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(st), torch.no_grad():
+        monkeypatch.delenv("NQA_ADISTS_STREAMS")
+        other = m(x, y, as_loss=False)
+    st.synchronize()
+    assert torch.equal(other, two)

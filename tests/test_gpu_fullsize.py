@@ -36,7 +36,8 @@ def models(dev):
         rep = d.calibrate(dev, 128, 128)
         print("auto calibration:", rep)
         assert rep["size_class"] == 0 and rep is d.calibrate(dev, 200, 200)  # cached per class
-        assert rep["choice"] == "f32s" and not rep["f16"]["ok"] and not rep["f32m2"]["admitted"]
+        # (every 16-bit rung but plain f16 shows outliers here, so nothing is admitted: a rung needs every slower one)
+        assert rep["choice"] == "f32s" and not rep["f16"]["admitted"] and not rep["f32m2"]["ok"]
         assert rep["budget"] == 6e-5 and rep["pairs"] == 384 and rep["source"].startswith(("measured", "file"))
         assert d.precision_for(200, 200) == "f32s" and d.precision_for(256, 256) == "f32s" and d.precision_for(1080, 1920) == "f16"
         big = d.calibrate(dev, 1080, 1920)

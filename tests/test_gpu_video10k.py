@@ -37,13 +37,17 @@ def test_video_1080p_three_batches_equal_direct_calls(dev):
         direct = torch.cat(direct)
     # a pair's score does not depend on its batch neighbours.  The statistics' block partition follows the batch size,
     # so with float taps (f32s, the mixed modes' deep stages) the float32 partial sums of a channel are grouped
-    # differently -- 1e-7; with half taps only (f16, f16w) every partial sum is exact and the scores are bit-equal
+    # differently -- 1e-7 (in every mode since round 4: the fused kernels of taps 1-2 sum in float32 per block)
     assert (scores - direct).abs().max().item() <= 3e-7, (scores - direct).abs().max().item()
     net16 = DISTS(vgg16_path="synth:1234", precision="f16").to(dev).eval()
     with torch.no_grad():
         a = torch.cat([net16(*video.synthetic_frames(range(lo, hi), H, W, dev)) for lo, hi in ((0, 8), (8, 13))])
         b2 = torch.cat([net16(*video.synthetic_frames(range(lo, hi), H, W, dev)) for lo, hi in ((0, 5), (5, 13))])
-    assert torch.equal(a, b2)
+        a2 = torch.cat([net16(*video.synthetic_frames(range(lo, hi), H, W, dev)) for lo, hi in ((0, 8), (8, 13))])
+    # the same calls again are bit-equal (fixed block -> tile partition, no atomics); a different split of the frames into
+    # batches moves the block boundaries of the fused conv + statistics kernels' float32 partial sums: 1e-7, as above
+    assert torch.equal(a, a2)
+    assert (a - b2).abs().max().item() <= 3e-7, (a - b2).abs().max().item()
     del net16
     assert torch.isfinite(scores).all() and scores.min() > 0 and len(set(scores.cpu().tolist())) == N
     cols = video.video_columns("DISTS", scores.cpu().numpy())
