@@ -1341,7 +1341,7 @@ __global__ __launch_bounds__(512) void conv1_regw_kernel(const float *__restrict
 //     the epilogue; float NHWC out (the tap the statistics and the pool read).
 // Same pipeline as conv1_regw_kernel: one barrier per tile, the two waves of a SIMD take conv1_1 (of the next tile) and
 // conv1_2 (of this one) in opposite order.  LDS: 2 x 65 280 (halo) + 2 x 5 760 (raw) + 16 384 (conv1_1 fragments) + 256
-// (bias) + 3 840 (raw-pixel staging) = 162 560 of the 163 840 bytes.
+// (bias) + 3 840 (raw-pixel staging) + 256 (conv1_2's bias) = 162 816 of the 163 840 bytes.
 __global__ __launch_bounds__(512) void conv1_regw_split_kernel(const float *__restrict__ x, const float *__restrict__ y,
                                                                int B, const char *__restrict__ w1m,
                                                                const float *__restrict__ bias1,
@@ -1357,6 +1357,7 @@ __global__ __launch_bounds__(512) void conv1_regw_split_kernel(const float *__re
   constexpr int RAWP = 40, RAW_ROWS = 9, RAW_PLANE = RAW_ROWS * RAWP * 8, RAW_BYTES = 2 * RAW_PLANE;  // hi plane, lo plane
   constexpr int RAW_OFF = 2 * SLOT, W1_OFF = RAW_OFF + 2 * RAW_BYTES, B1_OFF = W1_OFF + 2 * 4 * 2 * 64 * 16;
   constexpr int STG_OFF = B1_OFF + 256, STG_T = 320;  // float staging of the raw pixels, [3 planes][waves 0..4] (LDS-DMA)
+  constexpr int B2_OFF = STG_OFF + 3 * STG_T * 4;     // conv1_2's bias (the epilogue reads it: five registers fewer)
   constexpr int NG = 4, RW = 2, GPP = 2, NPASS = RW;  // 4 channel groups of 16; a wave: 2 rows x 2 groups of 16 columns
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [halo 0][halo 1][raw 0][raw 1][conv1_1 fragments][bias1]
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1387,14 +1388,14 @@ __global__ __launch_bounds__(512) void conv1_regw_split_kernel(const float *__re
 #pragma unroll
     for (int ks = 0; ks < 18; ++ks)
       wf[i][ks] = *reinterpret_cast<const u32x4 *>(wreg + ((((size_t)cg * 2 + i) * 18 + ks) * 64 + lane) * 16);
-  float bia[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) bia[e] = bias2[cg * 16 + 4 * c4 + e];
   const float winv2 = bias2[COUT];
 #pragma unroll
   for (int r = 0; r < 2; ++r)  // 8 KB = 512 x 16 B per term
     reinterpret_cast<u32x4 *>(smem + W1_OFF)[r * 512 + tid] = reinterpret_cast<const u32x4 *>(w1m)[r * 512 + tid];
-  if (tid < 64) reinterpret_cast<float *>(smem + B1_OFF)[tid] = bias1[tid] / w1inv;  // (exact: a power of two)
+  if (tid < 64) {
+    reinterpret_cast<float *>(smem + B1_OFF)[tid] = bias1[tid] / w1inv;  // (exact: a power of two)
+    reinterpret_cast<float *>(smem + B2_OFF)[tid] = bias2[tid];
+  }
   for (int i = tid; i < 2 * RAW_BYTES / 8; i += 512) reinterpret_cast<u32x2 *>(smem + RAW_OFF)[i] = (u32x2){0u, 0u};
 
   // ---- raw patch: thread t < 288 owns pixel (t / 36, t % 36) of the 8 x 36 patch; the float planes arrive by LDS-DMA
@@ -1526,60 +1527,85 @@ __global__ __launch_bounds__(512) void conv1_regw_split_kernel(const float *__re
     const char *slot = smem + (it & 1) * SLOT;
     const __amdgpu_buffer_rsrc_t orsrc =
         __builtin_amdgcn_make_buffer_rsrc(out + (size_t)n * H * W * COUT, 0, img_out_bytes, 0x00020000);
+    // BOTH rows of the wave in one k loop (round 4): a step = one halo row hr (0..3 below the wave's first output row) x
+    // one column tap kx x one 32-channel chunk; its four fragments (hi, lo x two 16-column groups) feed output row
+    // r = hr - ky for every kernel row ky that exists -- 6 MFMAs in the first and last halo row, 12 in the middle two.
+    // 24 steps and 96 fragment reads per tile instead of 36 and 144: with four waves of a CU in conv1_2 at once the
+    // row-at-a-time form asked the LDS for 128 clocks of reads per 96 clocks of MFMA.
     u32x4 bh[2][GPP], bl[2][GPP];
-    auto load_b = [&](const int (&q0)[GPP], int ks, u32x4(&h)[GPP], u32x4(&l)[GPP]) {
-      const int cc = ks / 9, t = ks - cc * 9, ky = t / 3, kx = t - ky * 3;
+    auto load_s = [&](const int (&q0)[GPP], int s, u32x4(&h)[GPP], u32x4(&l)[GPP]) {
+      const int cc = s / 12, hr = (s - cc * 12) / 3, kx = s - cc * 12 - hr * 3;
 #pragma unroll
       for (int g = 0; g < GPP; ++g) {
-        h[g] = *reinterpret_cast<const u32x4 *>(slot + q0[g] + (cc * CH_BYTES + (ky * HWD + kx) * PITCH));
-        l[g] = *reinterpret_cast<const u32x4 *>(slot + q0[g] + (cc * CH_BYTES + (ky * HWD + kx) * PITCH + LO));
+        h[g] = *reinterpret_cast<const u32x4 *>(slot + q0[g] + (cc * CH_BYTES + (hr * HWD + kx) * PITCH));
+        l[g] = *reinterpret_cast<const u32x4 *>(slot + q0[g] + (cc * CH_BYTES + (hr * HWD + kx) * PITCH + LO));
       }
     };
-    int q0[GPP];  // byte offset of this lane's hi fragment at tap (0,0), chunk 0, per 16-pixel group
+    int q0[GPP];  // byte offset of this lane's hi fragment at halo row ph * RW, tap kx = 0, chunk 0, per 16-pixel group
 #pragma unroll
     for (int g = 0; g < GPP; ++g) q0[g] = ((ph * RW) * HWD + g * 16 + l15) * PITCH + (c4 << 4);
     asm volatile("" : "+v"(q0[0]), "+v"(q0[1]));
-#pragma unroll 1
-    for (int pass = 0; pass < NPASS; ++pass) {
-      f32x4 acc[3][GPP];  // hi*hi | w_lo*a_hi | w_hi*a_lo
+    // hi*hi | the two cross terms w_lo*a_hi + w_hi*a_lo (2^-11 of the first: one accumulator, they are added in the end
+    // anyway), per group and output row -- 32 registers; a third set spilled
+    f32x4 acc[2][GPP][RW];
 #pragma unroll
-      for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int g = 0; g < GPP; ++g) acc[i][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      load_b(q0, 0, bh[0], bl[0]);
+      for (int g = 0; g < GPP; ++g)
 #pragma unroll
-      for (int ks = 0; ks < 18; ++ks) {
-        if (ks + 1 < 18) load_b(q0, ks + 1, bh[(ks + 1) & 1], bl[(ks + 1) & 1]);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int r = 0; r < RW; ++r) acc[i][g][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    constexpr int NSTEP = 2 * (RW + 2) * 3;
+    load_s(q0, 0, bh[0], bl[0]);
 #pragma unroll
-        for (int term = 0; term < 3; ++term)
+    for (int s2 = 0; s2 < NSTEP; ++s2) {
+      if (s2 + 1 < NSTEP) load_s(q0, s2 + 1, bh[(s2 + 1) & 1], bl[(s2 + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      const int cc = s2 / 12, hr = (s2 - cc * 12) / 3, kx = s2 - cc * 12 - hr * 3;
+#pragma unroll
+      for (int r = 0; r < RW; ++r) {
+        const int ky = hr - r;
+        if (ky < 0 || ky > 2) continue;
+        const int ks = cc * 9 + ky * 3 + kx;
+#pragma unroll
+        for (int term = 0; term < 3; ++term)  // (a cross accumulator's two MFMAs are a term apart: never back to back)
 #pragma unroll
           for (int g = 0; g < GPP; ++g)
-            acc[term][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+            acc[term ? 1 : 0][g][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
                 __builtin_bit_cast(f16x8, wf[term == 1 ? 1 : 0][ks]),
-                __builtin_bit_cast(f16x8, term == 2 ? bl[ks & 1][g] : bh[ks & 1][g]), acc[term][g], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+                __builtin_bit_cast(f16x8, term == 2 ? bl[s2 & 1][g] : bh[s2 & 1][g]), acc[term ? 1 : 0][g][r], 0, 0, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
 #pragma unroll
       for (int g = 0; g < GPP; ++g) {
-        const int gy = y0 + ph * RW + pass, gx = x0 + g * 16 + l15;
+        const int gy = y0 + ph * RW + r, gx = x0 + g * 16 + l15;
         const bool inside = gy < H && gx < W;
+        const f32x4 bia = *reinterpret_cast<const f32x4 *>(smem + B2_OFF + (cg * 16 + 4 * c4) * 4);
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          v[e] = fmaxf((acc[0][g][e] + (acc[1][g][e] + acc[2][g][e])) * winv2 + bia[e], 0.f);
+          v[e] = fmaxf((acc[0][g][r][e] + acc[1][g][r][e]) * winv2 + bia[e], 0.f);
         const unsigned off = inside ? (unsigned)(((gy * W + gx) * COUT + cg * 16 + 4 * c4) * 4) : kOOB;
+#ifdef NQA_SP_NO_STORE  // (timing-only: every store lands out of range)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), orsrc, off | kOOB, 0, 0);
+#else
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), orsrc, off, 0, 0);
+#endif
       }
-#pragma unroll
-      for (int g = 0; g < GPP; ++g) q0[g] += HWD * PITCH;  // next tile row
-      asm volatile("" : "+v"(q0[0]), "+v"(q0[1]));
-    }
   };
   for (int it = 0; it < my_tiles; ++it) {
     __syncthreads();
     raw_fetch(it + 2);  // lands under this tile's MFMAs
     const bool next = it + 1 < my_tiles;
+#if defined(NQA_SP_NO_P1)  // timing-only ablations (tools/gpu_split_ablate.sh; results are wrong on purpose)
+    conv1_2_tile(it);
+    (void)next;
+#elif defined(NQA_SP_NO_P2)
+    if (next) conv1_1_halo(it + 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (no stores in this ablation: the counted wait below would not hold)
+#else
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {  // (a loop, so that each phase's code exists once)
       if ((half == 0) == (wave < 4)) {
@@ -1590,6 +1616,7 @@ __global__ __launch_bounds__(512) void conv1_regw_split_kernel(const float *__re
         conv1_1_halo(it + 1);
       }
     }
+#endif
     raw_commit(it & 1, true);  // tile it+2's patch; 4 stores younger than its pixels in either phase order (see conv1_regw_kernel)
   }
 #endif
@@ -2476,7 +2503,7 @@ static int launch_conv1_regw(const float *x, const float *y, int B, int n, int H
 int conv1_fused_split(const float *x, const float *y, int B, int n, int H, int W, const void *packed_v, void *out,
                       hipStream_t st) {
   const char *packed = static_cast<const char *>(packed_v);
-  constexpr int LDS = 2 * 2 * 204 * 160 + 2 * 2 * 9 * 40 * 8 + 2 * 4 * 2 * 64 * 16 + 256 + 3 * 320 * 4;  // 162 560
+  constexpr int LDS = 2 * 2 * 204 * 160 + 2 * 2 * 9 * 40 * 8 + 2 * 4 * 2 * 64 * 16 + 256 + 3 * 320 * 4 + 256;  // 162 816
   static std::atomic<bool> attr_done_dev[64];
   std::atomic<bool> &attr_done = attr_done_dev[current_device() & 63];
   if (!attr_done) {
