@@ -428,6 +428,8 @@ def main():
     ap.add_argument("--only", action="store_true", help="skip the companion workloads of the N=1 line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=0, help="override pairs per GPU per step (experiments only)")
+    ap.add_argument("--vgg", default=VGG, help="VGG-16 weights of the headline line: a checkpoint path or a stand-in spec "
+                    "synth:<seed>[:<gain>] (profiling the default at another weight magnitude; the companions name their own)")
     ap.add_argument("--frames", type=int, default=10000, help="frames of the video10k workload")
     args = ap.parse_args()
 
@@ -510,7 +512,7 @@ def main():
         return
 
     dt, ktimes, prec, B, H, W, src = run_workload(args.workload, args.precision, args.steps, args.warmup, dev, world,
-                                                  rank, args.batch)
+                                                  rank, args.batch, vgg=args.vgg)
     dt, per = rank_times(dt)
     out = None
     if rank == 0:

@@ -1,5 +1,6 @@
-"""Condense the rocprofv3 output of tools/profile_r3.sh into the small summaries kept under profiles/ (r03_*), and into
-r03_traffic.json (with the sha256 of the profiled library), from which bench.py fills `roofline.traffic`."""
+"""Condense the rocprofv3 output of tools/profile_r3.sh / profile_r4.sh into the small summaries kept under profiles/
+(rNN_*), and into traffic.json (with the sha256 of the profiled library's sources), from which bench.py fills
+`roofline.traffic`.  usage: python tools/summarize_profile_r3.py <rocprof output dir> <summary dir>"""
 import collections
 import csv
 import glob
@@ -11,7 +12,7 @@ src, dst = sys.argv[1], sys.argv[2]
 os.makedirs(dst, exist_ok=True)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CONV = ("conv3x3_igemm_kernel", "conv3x3_regw_kernel", "conv3x3_regw128_kernel", "conv1_regw_kernel", "conv1_fused_kernel",
-        "conv1_tile_kernel", "conv1_regw_split_kernel")
+        "conv1_tile_kernel", "conv1_regw_split_kernel", "conv3x3_regw128_pool_kernel", "conv1_pool_kernel")  # (substring match)
 
 
 def short(name):
@@ -23,6 +24,8 @@ def klass(name):
         return "conv"
     if "pool_stats_kernel" in name:
         return "pool"
+    if "pool_seam_kernel" in name:
+        return "seam"
     return None
 
 
