@@ -6,6 +6,7 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 
 src, dst = sys.argv[1], sys.argv[2]
@@ -15,8 +16,27 @@ CONV = ("conv3x3_igemm_kernel", "conv3x3_regw_kernel", "conv3x3_regw128_kernel",
         "conv1_tile_kernel", "conv1_regw_split_kernel", "conv3x3_regw128_pool_kernel", "conv1_pool_kernel")  # (substring match)
 
 
+def demangle(name):
+    """rocprofv3 leaves some template instances mangled (_ZN3nqa<len><name>I<args>E...: binutils' c++filt does not know
+    the DF16_ in their signatures); kernel name and integer / bool template arguments are all that is needed here."""
+    m = re.match(r"_ZN3nqa(\d+)", name)
+    if not m:
+        return name
+    n = int(m.group(1))
+    base, rest = name[m.end():m.end() + n], name[m.end() + n:]
+    args = []
+    if rest.startswith("I"):
+        for kind, val in re.findall(r"L([ib])(\d+)E", rest[1:rest.index("EE") + 1] if "EE" in rest else ""):
+            args.append(("true" if val == "1" else "false") if kind == "b" else val)
+    return "nqa::" + base + ("<" + ", ".join(args) + ">" if args else "") + "("
+
+
+def ours(name):
+    return "nqa::" in name or name.startswith("_ZN3nqa")
+
+
 def short(name):
-    return name.replace("void nqa::", "").replace("nqa::", "").split("(")[0][:100]
+    return demangle(name).replace("void nqa::", "").replace("nqa::", "").split("(")[0][:100]
 
 
 def klass(name):
@@ -41,11 +61,11 @@ for d in sorted(glob.glob(f"{src}/trace_*")):
         f.write("kernel,calls,total_ms,avg_us,min_us,max_us,pct\n")
         tot = collections.defaultdict(lambda: [0, 0.0])
         for r in rows:
-            if "nqa::" not in r["Name"]:
+            if not ours(r["Name"]):
                 continue
             f.write(f"\"{short(r['Name'])}\",{r['Calls']},{float(r['TotalDurationNs'])/1e6:.3f},"
                     f"{float(r['AverageNs'])/1e3:.2f},{float(r['MinNs'])/1e3:.2f},{float(r['MaxNs'])/1e3:.2f},{r['Percentage']}\n")
-            k = klass(r["Name"])
+            k = klass(demangle(r["Name"]))
             if k:
                 tot[k][0] += int(r["Calls"])
                 tot[k][1] += float(r["TotalDurationNs"]) / 1e6
@@ -69,7 +89,7 @@ for d in sorted(glob.glob(f"{src}/pmc_FETCH_SIZE_*")):
     for cname in ("FETCH_SIZE", "WRITE_SIZE"):
         for f in glob.glob(f"{src}/pmc_{cname}_{wl}_{pr}/*/*_counter_collection.csv"):
             for r in csv.DictReader(open(f)):
-                if "nqa::" in r["Kernel_Name"] and r["Counter_Name"] == cname:
+                if ours(r["Kernel_Name"]) and r["Counter_Name"] == cname:
                     k = short(r["Kernel_Name"])
                     per[k][cname] += float(r["Counter_Value"])
                     cnt[k][cname] += 1
@@ -102,7 +122,7 @@ for d in sorted(glob.glob(f"{src}/pmc_mfma_*")):
     n = collections.Counter()
     for f in glob.glob(f"{d}/*/*_counter_collection.csv"):
         for r in csv.DictReader(open(f)):
-            if "nqa::" in r["Kernel_Name"]:
+            if ours(r["Kernel_Name"]):
                 k = short(r["Kernel_Name"])
                 agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
                 if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
