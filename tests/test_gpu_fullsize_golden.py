@@ -252,7 +252,8 @@ def test_synthetic_video_frames_are_index_addressed(dev):
 
 def test_rccl_one_rank():
     """The collective calls bench.py / sharding.py make at N > 1, on RCCL itself with one rank (a 1-GPU box cannot
-    host two): init with device_id, barrier, all_gather into the per-rank timing list, all_gather_into_tensor."""
+    host two): init with device_id, barrier, all_gather into the per-rank timing list, all_gather_into_tensor, the
+    object broadcast of DISTS' calibration verdict."""
     import subprocess
     import sys
     code = (
@@ -269,6 +270,12 @@ def test_rccl_one_rank():
         "out = sharding.gather_scores(scores, 10)\n"
         "full = sharding.score_frames_sharded(lambda lo, hi: scores[lo:hi] * 2, 10, 4, dev)\n"
         "assert torch.equal(out, scores) and al[0].item() == 1.5 and torch.equal(full, scores * 2)\n"
+        # the calibration verdict's object broadcast (sharding.agree_precision), on a real `auto` module
+        "os.environ['NQA_CAL_CACHE'] = 'off'\n"
+        "from nerf_qa_amd.DISTS_pytorch import DISTS\n"
+        "net = DISTS(vgg16_path='synth:1234').to(dev).eval()\n"
+        "mode = sharding.agree_precision(net, 160, 192, dev)\n"
+        "assert mode == net.precision_for(160, 192, dev) and net._agreed_report['agreed_over_ranks'] == 1\n"
         "dist.destroy_process_group(); print('RCCL one-rank ok')\n"
     ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)

@@ -10,12 +10,25 @@ import statistics
 import sys
 
 src = sys.argv[1]
+import re
+
 CONV = ("conv3x3_igemm_kernel", "conv3x3_regw_kernel", "conv3x3_regw128_kernel", "conv1_regw_kernel",
-        "conv1_regw_split_kernel")
+        "conv1_regw_split_kernel", "conv3x3_regw128_pool_kernel", "conv1_pool_kernel")  # (substring match; most specific last)
+
+
+def demangle(name):  # (see summarize_profile_r3.py: rocprofv3 leaves some template instances mangled)
+    m = re.match(r"_ZN3nqa(\d+)", name)
+    if not m:
+        return name
+    n = int(m.group(1))
+    base, rest = name[m.end():m.end() + n], name[m.end() + n:]
+    args = [("true" if v == "1" else "false") if k == "b" else v
+            for k, v in re.findall(r"L([ib])(\d+)E", rest[1:rest.index("EE") + 1] if rest.startswith("I") and "EE" in rest else "")]
+    return "nqa::" + base + ("<" + ", ".join(args) + ">" if args else "") + "("
 
 
 def short(name):
-    return name.replace("void nqa::", "").replace("nqa::", "").split("(")[0][:100]
+    return demangle(name).replace("void nqa::", "").replace("nqa::", "").split("(")[0][:100]
 
 
 print("Effective shader clock and matrix-pipe utilisation per conv kernel, B=8 1080p step (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES\n"
@@ -39,7 +52,7 @@ for d in sorted(glob.glob(f"{src}/pmc_mfma_*")):
             gui = v["GRBM_GUI_ACTIVE"] / 8
             per[v["k"]].append((gui / v["ns"], v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (gui * 1024)))
     print(os.path.basename(d)[len("pmc_mfma_"):])
-    for k in sorted(per, key=lambda k: (CONV.index(next(c for c in CONV if c in k)), k)):
+    for k in sorted(per, key=lambda k: (max(i for i, c in enumerate(CONV) if c in k), k)):
         clk = statistics.median(c for c, _ in per[k])
         util = statistics.median(u for _, u in per[k])
         print(f"  {k:<62} launches {len(per[k]):3d}  clock {clk:.2f} GHz  MfmaUtil {util:.3f}  "
