@@ -200,9 +200,6 @@ __global__ __launch_bounds__(512) void conv1_pool_kernel(const float *__restrict
   }
 
   // =============================== tail waves ===============================
-#ifdef NQA_S1_TAIL_PRIO  // (A/B: the tail waves, second-dispatched and the critical path, at a raised static issue priority)
-  __builtin_amdgcn_s_setprio(NQA_S1_TAIL_PRIO);
-#endif
   // conv1_1's 8 fragments and its bias (the accumulators' initial value)
   u32x4 w1f[4][2];
   f32x4 b1v[4];
