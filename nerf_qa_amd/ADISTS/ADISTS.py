@@ -17,11 +17,12 @@ after normalisation, and the same channel rounded to exactly dead contributes T 
 flip moves the score by a channel weight, ~5e-4 (measured; DISTS' statistics have no such edge).
 precision="f16" stays available as the opt-in fast mode (3x the throughput at 1080p).
 
-as_loss=True in the reference runs the pyramids WITH autograd (:139-141).  DISTS(require_grad=True) has its backward
-through the HIP pyramid since round 3 (nerf_qa_amd/autograd.py); A-DISTS' windowed pass, entropy weights and probability
-chain have none yet, so when a gradient would actually be needed (grad mode on and x or y requires grad) the call raises
-NotImplementedError; otherwise the value 1-mean(D) is returned (there is no graph to lose).  No script of the reference
-calls it that way (prep.py:186, test2_prep.py:151 pass as_loss=False).  as_map=True returns the
+as_loss=True in the reference runs the pyramids WITH autograd (:139-141).  Here, when a gradient is actually needed (grad mode
+on and x or y requires grad), the tapped maps come from autograd.PyramidTaps (HIP forward, HIP backward through the 13 conv
+layers in f32s, as for DISTS(require_grad=True)) and the head -- texture probabilities, entropy weights, windowed T / S -- is
+evaluated in torch operations on the GPU (ADISTS/head.py) so that autograd differentiates it; the value returned is still the
+fused kernel's.  Otherwise the value 1-mean(D) comes from the fused kernel alone (there is no graph to lose).  No script of
+the reference calls it with a gradient (prep.py:186, test2_prep.py:151 pass as_loss=False).  as_map=True returns the
 reference's [B,B,H,W] distortion map (:163,188-193) from one extra kernel.
 """
 from __future__ import annotations
@@ -99,9 +100,12 @@ class ADISTS(torch.nn.Module):
             return self.precision
         return "f32" if h * w < AUTO_EXACT_PIXELS else "f32s"
 
+    def _weights_key(self, dev):
+        return (str(dev),) + tuple((m.weight._version, m.weight.data_ptr()) for m in self._conv_modules())
+
     def _packed_weights(self, dev, prec):
         convs = self._conv_modules()
-        key = (str(dev),) + tuple((m.weight._version, m.weight.data_ptr()) for m in convs)
+        key = self._weights_key(dev)
         hit = self._packed.get(prec)
         if hit is None or hit[0] != key:
             blob = ops.pack_vgg_weights([(m.weight, m.bias) for m in convs], prec)
@@ -147,6 +151,26 @@ class ADISTS(torch.nn.Module):
             main.wait_stream(st)
         return torch.cat(outs)
 
+    def _loss_with_grad(self, x, y):
+        """1 - mean(D) WITH its gradient towards x and y (ADISTS.py:139-141, 195).  The tapped maps come from
+        autograd.PyramidTaps (HIP forward; HIP backward through the conv stack in f32s), the head is head.adists_d in
+        torch operations, which autograd differentiates.  The VALUE returned is the scoring path's own (the fused
+        kernel, same precision policy as as_loss=False), with the torch expression's gradient attached."""
+        from .. import autograd
+        from . import head
+        tx = autograd.PyramidTaps.apply(x, self) if x.requires_grad else self._taps_nograd(x)
+        ty = autograd.PyramidTaps.apply(y, self) if y.requires_grad else self._taps_nograd(y)
+        d = head.adists_d([x.float()] + list(tx), [y.float()] + list(ty), self.window_size)
+        loss = 1 - d.mean()
+        with torch.no_grad():
+            value = 1 - self._score(x.detach(), y.detach(), self.precision_for(x.shape[-2], x.shape[-1])).mean()
+        return value + (loss - loss.detach())
+
+    @torch.no_grad()
+    def _taps_nograd(self, img):
+        taps = ops.vgg_pyramid(img.float(), self._packed_weights(img.device, "f32s"), "f32s", self._ws)
+        return [ops.nhwc_to_nchw_f32(t, "f32s") for t in taps]
+
     def forward_once(self, x):
         prec = self.precision_for(x.shape[-2], x.shape[-1])
         taps = ops.vgg_pyramid(x, self._packed_weights(x.device, prec), prec, self._ws)
@@ -154,10 +178,8 @@ class ADISTS(torch.nn.Module):
 
     def forward(self, x, y, as_loss=True, as_map=False):
         assert x.shape == y.shape
-        if as_loss and torch.is_grad_enabled() and (x.requires_grad or y.requires_grad):
-            raise NotImplementedError("ADISTS(as_loss=True) on grad-requiring inputs needs a backward pass through "
-                                      "the VGG pyramid (ADISTS.py:139-141), which this build does not have; call it "
-                                      "under torch.no_grad() or with as_loss=False for the value")
+        if as_loss and not as_map and torch.is_grad_enabled() and (x.requires_grad or y.requires_grad):
+            return self._loss_with_grad(x, y)
         prec = self.precision_for(x.shape[-2], x.shape[-1])
         if as_map:
             # (:163,188-189,193) the reference's (B,H,W) + (B,1,H,W) addition broadcasts to (B,B,H,W)

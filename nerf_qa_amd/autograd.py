@@ -1,4 +1,5 @@
-"""Image gradients of DISTS: `DISTS.forward(x, y, require_grad=True)` (nerf_qa/DISTS_pytorch/DISTS_pt.py:105-108).
+"""Image gradients of DISTS: `DISTS.forward(x, y, require_grad=True)` (nerf_qa/DISTS_pytorch/DISTS_pt.py:105-108), and of
+A-DISTS' default `as_loss=True` (nerf_qa/ADISTS/ADISTS.py:139-141) through `PyramidTaps`.
 
 The reference gets them by running forward_once with autograd enabled.  Here the VALUES (S1, S2) come from the fused
 HIP forward as always; when a gradient is asked for, `DistsSimilarities.backward` re-runs the pyramid layer by layer in
@@ -73,16 +74,12 @@ def _backward_blobs(module, dev):
 
 
 @torch.no_grad()
-def dists_backward(module, x, y, g1, g2):
-    """(dL/dx, dL/dy) given dL/dS1, dL/dS2 (each (B, 1475)) for the pairs (x, y), float32 (B,3,H,W) on the GPU."""
-    dev = x.device
-    b = x.shape[0]
+def pyramid_keep(module, imgs):
+    """The pyramid of `imgs` (n,3,H,W float) again, layer by layer in f32s, keeping every activation:
+    (acts {layer: NHWC}, taps [5 float NHWC maps], pooled [4 split16 maps])."""
     prec = "f32s"
-    packed = module._packed_weights(dev, prec)
-    blobs, w0 = _backward_blobs(module, dev)
-    xy = torch.cat([x, y]).float().contiguous()
-    # ---- the forward again, layer by layer, keeping every activation ----
-    acts = {0: ops.conv1_1(xy, packed, prec)}  # split16 (2B,H,W,64)
+    packed = module._packed_weights(imgs.device, prec)
+    acts = {0: ops.conv1_1(imgs, packed, prec)}  # split16 (n,H,W,64)
     taps, pooled = [], []
     inp = acts[0]
     for l in range(1, 13):
@@ -94,20 +91,25 @@ def dists_backward(module, x, y, g1, g2):
             if l != 12:
                 pooled.append(ops.l2pool(out, prec))  # split16
                 inp = pooled[-1]
-    # ---- gradients of the statistics with respect to the six taps ----
-    off = 3
-    g_taps = []
-    for k, t in enumerate(taps):
-        c = t.shape[-1]
-        gx, gy = _stats_grad(t[:b], t[b:], g1[:, off:off + c], g2[:, off:off + c], dims=(1, 2))
-        g_taps.append(torch.cat([gx, gy]).contiguous())
-        off += c
-    gx0, gy0 = _stats_grad(x.float(), y.float(), g1[:, :3], g2[:, :3], dims=(2, 3))  # tap 0 = the raw image (NCHW)
-    # ---- back through the pyramid ----
-    # The data-gradient convolutions take split16 (f16 hi + lo) operands, whose dynamic range is f16's -- and image
-    # gradients of a mean-type score are tiny (~1/N per pixel: 1e-8 at a few thousand pixels, where a half is already
-    # subnormal).  Everything below is LINEAR in g, so g is renormalised by an exact power of two before every layer
-    # (max |g| into [128, 256)) and the accumulated exponent taken out of the final image gradient.
+    return acts, taps, pooled
+
+
+@torch.no_grad()
+def pyramid_backward(module, acts, taps, pooled, g_taps):
+    """d/d(image) (n,3,H,W) of a scalar whose gradients with respect to the five tapped maps are `g_taps` (float NHWC, as
+    `taps`), through the activations pyramid_keep kept.
+
+    The data-gradient convolutions take split16 (f16 hi + lo) operands, whose dynamic range is f16's -- and image
+    gradients of a mean-type score are tiny (~1/N per pixel: 1e-8 at a few thousand pixels, where a half is already
+    subnormal).  Everything here is LINEAR in g, so g is renormalised by an exact power of two before every layer
+    (max |g| into [128, 256)) and the accumulated exponent taken out of the final image gradient."""
+    blobs, w0 = _backward_blobs(module, taps[0].device)
+    # A tapped map is a ReLU output: where it is 0 the gradient stops (torch's own rule, grad * (out > 0)).  Applied HERE,
+    # before anything is renormalised: A-DISTS' F.normalize gives an exactly dead channel a gradient of the order of
+    # 1 / eps = 1e12 times its upstream (5e8 measured on a 40 x 56 pair), which the mask discards -- but a renormalisation
+    # by max |g| taken with it in would push every live gradient below the halves' range first.
+    g_taps = [g * (t > 0) for g, t in zip(g_taps, taps)]
+
     def normalise(t, k_total):
         mx = float(t.abs().max())
         if mx > 0 and math.isfinite(mx):
@@ -122,13 +124,56 @@ def dists_backward(module, x, y, g1, g2):
         g = ops.conv3x3_split(gm, blobs[l], ops.CONV_CIN[l], relu=False)  # gradient w.r.t. the layer's input
         if l in (2, 4, 7, 10):  # the input was the L2-pool of the previous stage's tap
             s = ops.CONV_STAGE[l]
-            gt = g_taps[s - 1] * (2.0 ** K)  # the tap's own statistics gradient, in the running scale
+            gt = g_taps[s - 1] * (2.0 ** K)  # the tap's own gradient, in the running scale
             ops.l2pool_backward(taps[s - 1], pooled[s - 1], g, gt)  # gt += pool gradient
             g = gt
         g, K = normalise(g, K)
     gm = g * (ops.split16_decode(acts[0]) > 0)  # d(ReLU) of relu1_1, float
-    gimg = ops.conv1_1_backward(gm, w0) * (2.0 ** -K)  # (2B,3,H,W), the input normalisation included
+    return ops.conv1_1_backward(gm, w0) * (2.0 ** -K)  # (n,3,H,W), the input normalisation included
+
+
+@torch.no_grad()
+def dists_backward(module, x, y, g1, g2):
+    """(dL/dx, dL/dy) given dL/dS1, dL/dS2 (each (B, 1475)) for the pairs (x, y), float32 (B,3,H,W) on the GPU."""
+    b = x.shape[0]
+    xy = torch.cat([x, y]).float().contiguous()
+    acts, taps, pooled = pyramid_keep(module, xy)
+    # ---- gradients of the statistics with respect to the six taps ----
+    off = 3
+    g_taps = []
+    for k, t in enumerate(taps):
+        c = t.shape[-1]
+        gx, gy = _stats_grad(t[:b], t[b:], g1[:, off:off + c], g2[:, off:off + c], dims=(1, 2))
+        g_taps.append(torch.cat([gx, gy]).contiguous())
+        off += c
+    gx0, gy0 = _stats_grad(x.float(), y.float(), g1[:, :3], g2[:, :3], dims=(2, 3))  # tap 0 = the raw image (NCHW)
+    gimg = pyramid_backward(module, acts, taps, pooled, g_taps)
     return gimg[:b] + gx0, gimg[b:] + gy0
+
+
+class PyramidTaps(torch.autograd.Function):
+    """images (n,3,H,W) -> the five tapped maps relu1_2 .. relu5_3 as float NCHW tensors, differentiable in the images
+    (ADISTS.forward(as_loss=True) runs forward_once WITH autograd, ADISTS.py:139-141; the frozen VGG weights get no
+    gradient).  Values from the fused f32s forward; backward = pyramid_keep + pyramid_backward."""
+
+    @staticmethod
+    def forward(ctx, imgs, module):
+        prec = "f32s"
+        imgs = imgs.float().contiguous()
+        taps = ops.vgg_pyramid(imgs, module._packed_weights(imgs.device, prec), prec, module._ws)
+        ctx.module = module
+        ctx.save_for_backward(imgs)
+        return tuple(ops.nhwc_to_nchw_f32(t, prec) for t in taps)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        (imgs,) = ctx.saved_tensors
+        if not ctx.needs_input_grad[0]:
+            return None, None
+        acts, taps, pooled = pyramid_keep(ctx.module, imgs)
+        g_taps = [(torch.zeros_like(t) if g is None else g.detach().float().permute(0, 2, 3, 1).contiguous())
+                  for g, t in zip(grads, taps)]
+        return pyramid_backward(ctx.module, acts, taps, pooled, g_taps), None
 
 
 class DistsSimilarities(torch.autograd.Function):

@@ -154,13 +154,16 @@ def test_csv_writer_layout(tmp_path):
     assert list(sq.columns) == ["x", "DISTS_square", "DISTS_square_std", "DISTS_square_min", "DISTS_square_max"]
 
 
-def test_adists_as_loss_needs_no_silent_graph():
-    """as_loss=True (the reference's default) runs WITH autograd in the reference (ADISTS.py:139-141); without a
-    VGG backward the drop-in must refuse grad-requiring inputs instead of returning a graph-less scalar."""
+def test_adists_as_loss_never_returns_a_silent_graphless_scalar():
+    """as_loss=True (the reference's default) runs WITH autograd in the reference (ADISTS.py:139-141).  Since round 4 the
+    drop-in has that gradient (HIP pyramid backward + the head in torch operations, tests/test_gpu_backward.py); on CPU
+    tensors it refuses like every other entry point -- there is no CPU fallback -- instead of returning a scalar
+    without a graph."""
+    import nerf_qa_amd
     from nerf_qa_amd.ADISTS import ADISTS
     m = ADISTS()
     x = torch.rand(1, 3, 32, 32, requires_grad=True)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(nerf_qa_amd.NqaError):
         m(x, torch.rand(1, 3, 32, 32))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(nerf_qa_amd.NqaError):
         m(torch.rand(1, 3, 32, 32), x, as_loss=True)

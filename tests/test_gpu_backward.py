@@ -125,3 +125,49 @@ def test_gradient_only_where_asked_and_with_alpha_beta(dev, oracle_convs):
     s2 = m(x2, yd)  # require_grad=False: value only
     s2.backward()
     assert x2.grad is None and abs(s2.item() - s.item()) <= 1e-4
+
+
+@pytest.mark.parametrize("h,w,kinds", [(40, 56, ("noise10", "blur")), (96, 112, ("blur", "noise10")), (63, 85, ("indep", "noise02"))],
+                         ids=["40x56", "96x112", "63x85_ragged"])
+def test_adists_loss_gradients_match_autograd_over_the_oracle(h, w, kinds, dev, oracle_convs):
+    """ADISTS.forward(x, y) -- as_loss=True, the reference's default -- under autograd (ADISTS.py:139-141, 195): the loss
+    and its image gradients against torch autograd over the CPU oracle's pyramid + head (windowed stages and the global
+    fall-back of the small deep maps both occur at these sizes)."""
+    from nerf_qa_amd import synth
+    from nerf_qa_amd.ADISTS import ADISTS
+    from oracle import adists_oracle as ao
+    from oracle import dists_oracle as do
+    m = ADISTS(vgg16_path="synth:1234").to(dev).eval()
+    xn, yn = synth.frame_batch([21, 22], h, w, list(kinds))
+    xc, yc = torch.from_numpy(xn).requires_grad_(), torch.from_numpy(yn).requires_grad_()
+    ref = ao.adists_from_feats(do.vgg_pyramid(xc, oracle_convs), do.vgg_pyramid(yc, oracle_convs), as_loss=True)
+    ref.backward()
+    xd, yd = torch.from_numpy(xn).to(dev).requires_grad_(), torch.from_numpy(yn).to(dev).requires_grad_()
+    got = m(xd, yd)  # as_loss=True
+    assert got.dim() == 0 and got.requires_grad and abs(got.item() - ref.item()) <= 1e-4
+    with torch.no_grad():
+        assert abs(got.item() - m(xd.detach(), yd.detach()).item()) <= 1e-7  # the value IS the scoring path's
+    got.backward()
+    for name, gd, gc in (("x", xd.grad, xc.grad), ("y", yd.grad, yc.grad)):
+        scale = gc.abs().max().item()
+        d = gd.cpu() - gc
+        err, rms = d.abs().max().item() / scale, d.pow(2).mean().sqrt().item() / gc.pow(2).mean().sqrt().item()
+        cos = F.cosine_similarity(gd.cpu().flatten(), gc.flatten(), dim=0).item()
+        print(f"\nA-DISTS {h}x{w} d/d{name}: max|grad| {scale:.3e}  max err / max {err:.2e}  rms err / rms {rms:.2e}  cosine {cos:.8f}")
+        assert err <= 2e-2 and rms <= 3e-3 and cos >= 0.99999, (name, err, rms, cos)  # (measured: 1e-5 .. 9e-3, 1e-5 .. 1e-3)
+
+
+def test_adists_gradient_only_where_asked(dev):
+    from nerf_qa_amd import synth
+    from nerf_qa_amd.ADISTS import ADISTS
+    m = ADISTS(vgg16_path="synth:1234").to(dev).eval()
+    xn, yn = synth.frame_batch([5], 48, 64)
+    xd, yd = torch.from_numpy(xn).to(dev), torch.from_numpy(yn).to(dev).requires_grad_()
+    loss = m(xd, yd)  # only the render carries a gradient (the NeRF-training use)
+    loss.backward()
+    assert yd.grad is not None and yd.grad.abs().max().item() > 0 and xd.grad is None
+    with torch.no_grad():
+        assert not m(xd, yd).requires_grad  # no grad mode: the fused kernel alone
+    assert not m(xd, yd.detach()).requires_grad  # nothing requires grad: likewise
+    s = m(xd, yd, as_loss=False)  # per-pair scores never carry a graph (ADISTS.py:142-145 runs them under no_grad)
+    assert s.shape == (1,) and not s.requires_grad
