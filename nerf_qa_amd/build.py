@@ -21,7 +21,7 @@ RESOURCES_BUILD = os.path.join(HERE, "build", "kernel_resources.json")  # what t
 # the vmcnt counter with the LDS-DMA rings, so a spill makes every counted wait over-wait): a build in which one of
 # these uses scratch FAILS.  Matched against the demangled-ish kernel name in the compiler's remark.
 NO_SCRATCH = ("conv3x3_igemm_kernel", "conv3x3_regw_kernel", "conv3x3_regw128_kernel", "conv3x3_regw128_pool_kernel", "conv1_pool_kernel", "conv1_regw_kernel",
-              "conv1_fused_kernel", "conv1_tile_kernel", "conv1_split_kernel", "conv1_regw_split_kernel", "pool_stats_kernel",
+              "conv1_fused_kernel", "conv1_tile_kernel", "conv1_split_kernel", "conv1_regw_split_kernel", "conv3x3_regw_split_kernel", "pool_stats_kernel",
               "adists_window_lds_kernel", "adists_window_planar_kernel", "l2pool_kernel", "stats_nhwc_kernel")
 
 

@@ -96,9 +96,9 @@ size_t layer0_mfma_offset(int prec) { return layer_offset(0, prec) + align_up(27
 // (144 VGPRs) once per persistent block.  Appended behind the ordinary layers.
 // (NQA_PREC_F32M: the same fragments for 16 channels per group, once as the f16 `hi` and once as the `lo` part of the
 // scaled weights: [cout/16][part][k-steps][64 lanes][8 halfs])
-// (NQA_PREC_F32S: conv1_2 alone, in the two-term form, for the fused stage-1 kernel conv1_regw_split_kernel)
+// (NQA_PREC_F32S: conv1_2 and conv2_1 in the two-term form, for conv1_regw_split_kernel and conv3x3_regw_split_kernel)
 size_t regw_bytes(int layer, int prec) {
-  if (prec == NQA_PREC_F32S) return layer == 1 ? (size_t)64 * 64 * 9 * 2 * 2 : 0;
+  if (prec == NQA_PREC_F32S) return layer <= 2 ? (size_t)kConvs[layer].cout * 64 * 9 * 2 * 2 : 0;  // conv1_2, conv2_1
   return (size_t)kConvs[layer].cout * kConvs[layer].cin * 9 * 2 * (is_mixed(prec) ? 2 : 1);
 }
 static const int kRegwFirst = 1, kRegwLast = 4;  // conv1_2, conv2_1 (Cin 64); conv2_2, conv3_1 (Cin 128)
@@ -587,7 +587,7 @@ int nqa_pack_vgg_weights(const float *const w_host[NQA_NUM_CONVS], const float *
               w1[((((size_t)i * 2 + m) * 2 + part) * 64 + lane) * 8 + j] = part == 0 ? hi : f32_to_f16(v - f16_to_f32(hi));
             }
     // two-term register fragments of layers 1..4 (conv3x3_regw_kernel<.., NTERM = 2> and regw128; f32s: conv1_2 only)
-    for (int l = kRegwFirst; l <= (prec == NQA_PREC_F32S ? kRegwFirst : kRegwLast); ++l) {
+    for (int l = kRegwFirst; l <= (prec == NQA_PREC_F32S ? kRegwFirst + 1 : kRegwLast); ++l) {
       const ConvSpec &cs = kConvs[l];
       const int nks = cs.cin / 32 * 9;
       const float wscale = ldexpf(1.f, weight_scale_exp(w_host[l], (size_t)cs.cout * cs.cin * 9));  // (as the layer's rows)

@@ -1623,6 +1623,181 @@ __global__ __launch_bounds__(512) void conv1_regw_split_kernel(const float *__re
 }
 
 // ---------------------------------------------------------------------------------
+// conv2_1 in f32s with the WEIGHTS IN REGISTERS (round 4): conv1_regw_split_kernel's conv1_2 on a halo that comes from
+// memory.
+// ---------------------------------------------------------------------------------
+// The implicit GEMM runs this layer (64 -> 128 channels, 18 k-steps) at 0.42 of the issued-MFMA peak: its stages are
+// shorter than an LDS-DMA round trip, as in the 16-bit modes before conv3x3_regw_kernel.  Here a wave keeps the (hi, lo)
+// fragments of 16 output channels (144 VGPRs, the two-term blob format of conv1_2), a block of 8 waves covers 64 output
+// channels x a 4 x 32 tile (4 channel groups x 2 row pairs), and the two 64-channel halves of the layer are separate
+// blocks that share an XCD and walk the same tile sequence (the second one finds the halo in L2).  The input is the
+// split16 pooled tap (256 B per pixel); LDS-DMA brings the 6 x 34 halo patch in as the records conv1_2 reads --
+// [32 channels hi | 32 channels lo | 32 B pad] per 32-channel chunk, 160 B, conflict-free for a ds_read_b128 of 16
+// consecutive pixels -- by giving each 16-byte item its own global address (the split16 record interleaves hi and lo
+// per 8 channels; the permutation costs nothing).  Two slots (130 560 B), the next tile's patch requested one tile
+// ahead, one barrier and one counted vmcnt per tile.  The k loop is conv1_2's (both rows of the wave per step, the
+// cross terms in one accumulator); split16 records out (conv2_1 is not a tapped layer).
+__global__ __launch_bounds__(512) void conv3x3_regw_split_kernel(const char *__restrict__ in, const char *__restrict__ wreg,
+                                                                 const float *__restrict__ bias, char *__restrict__ out,
+                                                                 int H, int W, int tiles_x, int tiles_y, int total_tiles,
+                                                                 int cout) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int CIN = 64, TH = 4, TW = 32, HWD = TW + 2, NQ = (TH + 2) * HWD;  // 204 halo pixels
+  constexpr int PITCH = 160, LO = 64, CH_BYTES = NQ * PITCH, SLOT = 2 * CH_BYTES;
+  constexpr int ITEMS = 2 * NQ * (PITCH / 16), ROUNDS = (ITEMS + 511) / 512;  // 4 080 sixteen-byte items, 8 DMA rounds
+  constexpr int RW = 2, GPP = 2, NSTORE = 2 * RW * GPP;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [halo slot 0][halo slot 1]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, c4 = lane >> 4;
+  const int cg = wave & 3, ph = wave >> 2;
+  const int nh = cout >> 6;  // 64-channel halves of the layer (conv2_1: 2)
+
+  // blocks with the same (XCD, stream) and different halves walk the same tiles
+  const int nblk = gridDim.x, xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+  const int half = jb % nh, stream = jb / nh, streams = (nblk >> 3) / nh;
+  const int t_lo = (int)((long)total_tiles * xcd / 8), t_hi = (int)((long)total_tiles * (xcd + 1) / 8);
+  const int my_tiles = t_lo + stream < t_hi ? (t_hi - t_lo - stream - 1) / streams + 1 : 0;
+  if (my_tiles == 0) return;  // (block-uniform)
+  auto tile_coords = [&](int it, int &n, int &x0, int &y0) {
+    const int t = t_lo + stream + it * streams;
+    n = t / (tiles_x * tiles_y);
+    const int t2 = t - n * (tiles_x * tiles_y), by = t2 / tiles_x;
+    x0 = (t2 - by * tiles_x) * TW;
+    y0 = by * TH;
+  };
+
+  u32x4 wf[2][18];  // [hi | lo][k-step] of this wave's 16 output channels
+  const int cgg = half * 4 + cg;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int ks = 0; ks < 18; ++ks)
+      wf[i][ks] = *reinterpret_cast<const u32x4 *>(wreg + ((((size_t)cgg * 2 + i) * 18 + ks) * 64 + lane) * 16);
+  const f32x4 bia = *reinterpret_cast<const f32x4 *>(bias + cgg * 16 + 4 * c4);
+  const float winv = bias[cout];
+
+  // DMA plan: item j = round * 512 + tid is 16 bytes of LDS; record j / 10 = (chunk, halo pixel), part j % 10: parts 0..3
+  // the chunk's hi halves of channels 8 p .., parts 4..7 its lo halves, 8..9 the pad.  Packed per round: halo row (4 bits),
+  // halo column (6 bits), byte offset inside the pixel's split16 record (9 bits), bit 19 = a live item.
+  int plan[ROUNDS];
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
+    const int j = r * 512 + tid, rec = j / 10, part = j - rec * 10;
+    const int cc = rec >= NQ ? 1 : 0, q = rec - cc * NQ, hy = q / HWD, hx = q - hy * HWD;
+    const int p4 = part & 3, piece = (p4 >> 1) * 4 + (p4 & 1) + (part >= 4 ? 2 : 0);  // 16-byte piece of the 128-byte chunk
+    const bool live = j < ITEMS && part < 8;
+    plan[r] = live ? ((hy & 15) | (hx << 4) | ((cc * 128 + piece * 16) << 10) | (1 << 19)) : 0;
+  }
+  const unsigned kOOB = 0x80000000u;
+  const unsigned img_in_bytes = (unsigned)H * (unsigned)W * (unsigned)(CIN * 4);
+  const unsigned img_out_bytes = (unsigned)H * (unsigned)W * (unsigned)cout * 4u;
+  auto issue_halo = [&](int it, int slot_idx) {
+    char *slot = smem + slot_idx * SLOT;
+    const bool real = it < my_tiles;  // past the last tile: the same number of pieces, all out of range
+    int n = 0, x0 = 0, y0 = 0;
+    if (real) tile_coords(it, n, x0, y0);
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(in + (size_t)n * H * W * (CIN * 4)), 0, img_in_bytes, 0x00020000);
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+      const int pl = plan[r];
+      const int gy = y0 - 1 + (pl & 15), gx = x0 - 1 + ((pl >> 4) & 63);
+      const bool live = real && (pl >> 19);
+      const bool ok = live && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      const unsigned off = ok ? (unsigned)((gy * W + gx) * (CIN * 4) + ((pl >> 10) & 511)) : kOOB;
+      // (the last 16 lanes of the last round would address LDS BEHIND the slot -- record (0, 0) of the other slot, which
+      // the block is reading at that moment.  An out-of-range offset is not enough there: with those lanes left in the
+      // instruction single pixels came out wrong in ~1 of 2 launches on ragged maps, tools/gpu_regw_split_check.py;
+      // masked out of EXEC the instruction still counts once in vmcnt)
+      if (r * 512 + tid < ITEMS)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t *)(slot + r * 8192 + wave * 1024), 16, off, 0, 0, 0);
+      if (live && !ok)  // zero padding (the DMA transfers nothing for an out-of-range lane)
+        *reinterpret_cast<u32x4 *>(slot + (r * 512 + tid) * 16) = (u32x4){0u, 0u, 0u, 0u};
+    }
+  };
+
+  issue_halo(0, 0);
+  for (int it = 0; it < my_tiles; ++it) {
+    int n, x0, y0;
+    tile_coords(it, n, x0, y0);
+    // tile `it`'s patch was requested before the previous tile's stores: everything but those has retired
+    if (it == 0)
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NSTORE) : "memory");
+    issue_halo(it + 1, (it + 1) & 1);  // into the slot tile it - 1 read, which every wave left before the barrier
+    const char *slot = smem + (it & 1) * SLOT;
+    const __amdgpu_buffer_rsrc_t orsrc =
+        __builtin_amdgcn_make_buffer_rsrc(out + (size_t)n * H * W * cout * 4, 0, img_out_bytes, 0x00020000);
+    u32x4 bh[2][GPP], bl[2][GPP];
+    auto load_s = [&](const int (&q0)[GPP], int s, u32x4(&h)[GPP], u32x4(&l)[GPP]) {
+      const int cc = s / 12, hr = (s - cc * 12) / 3, kx = s - cc * 12 - hr * 3;
+#pragma unroll
+      for (int g = 0; g < GPP; ++g) {
+        h[g] = *reinterpret_cast<const u32x4 *>(slot + q0[g] + (cc * CH_BYTES + (hr * HWD + kx) * PITCH));
+        l[g] = *reinterpret_cast<const u32x4 *>(slot + q0[g] + (cc * CH_BYTES + (hr * HWD + kx) * PITCH + LO));
+      }
+    };
+    int q0[GPP];
+#pragma unroll
+    for (int g = 0; g < GPP; ++g) q0[g] = ((ph * RW) * HWD + g * 16 + l15) * PITCH + (c4 << 4);
+    asm volatile("" : "+v"(q0[0]), "+v"(q0[1]));
+    f32x4 acc[2][GPP][RW];  // hi*hi | the two cross terms, per group and output row
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int g = 0; g < GPP; ++g)
+#pragma unroll
+        for (int r = 0; r < RW; ++r) acc[i][g][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    constexpr int NSTEP = 2 * (RW + 2) * 3;
+    load_s(q0, 0, bh[0], bl[0]);
+#pragma unroll
+    for (int s2 = 0; s2 < NSTEP; ++s2) {
+      if (s2 + 1 < NSTEP) load_s(q0, s2 + 1, bh[(s2 + 1) & 1], bl[(s2 + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      const int cc = s2 / 12, hr = (s2 - cc * 12) / 3, kx = s2 - cc * 12 - hr * 3;
+#pragma unroll
+      for (int r = 0; r < RW; ++r) {
+        const int ky = hr - r;
+        if (ky < 0 || ky > 2) continue;
+        const int ks = cc * 9 + ky * 3 + kx;
+#pragma unroll
+        for (int term = 0; term < 3; ++term)
+#pragma unroll
+          for (int g = 0; g < GPP; ++g)
+            acc[term ? 1 : 0][g][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                __builtin_bit_cast(f16x8, wf[term == 1 ? 1 : 0][ks]),
+                __builtin_bit_cast(f16x8, term == 2 ? bl[s2 & 1][g] : bh[s2 & 1][g]), acc[term ? 1 : 0][g][r], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // descale, bias, ReLU; channels c = 16 cgg + 4 c4 .. + 3 of a pixel's split16 record: hi halves at
+    // (c >> 4) * 64 + ((c >> 3) & 1) * 16 + (c & 7) * 2, lo halves 32 bytes behind (store_split4)
+    const unsigned rec_off = (unsigned)(cgg * 64 + (c4 >> 1) * 16 + (c4 & 1) * 8);
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+      for (int g = 0; g < GPP; ++g) {
+        const int gy = y0 + ph * RW + r, gx = x0 + g * 16 + l15;
+        const bool inside = gy < H && gx < W;
+        typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+        h4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = fmaxf((acc[0][g][r][e] + acc[1][g][r][e]) * winv + bia[e], 0.f);
+          hi[e] = (_Float16)v;
+          lo[e] = (_Float16)(v - (float)hi[e]);
+        }
+        const unsigned off = inside ? (unsigned)(gy * W + gx) * (unsigned)(cout * 4) + rec_off : kOOB;
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hi), orsrc, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lo), orsrc, off, 32, 0);
+      }
+  }
+#endif
+}
+
+// ---------------------------------------------------------------------------------
 // conv1_1 + conv1_2 fused (16-bit modes): the whole of stage 1 without the 64-channel
 // full-resolution intermediate ever touching HBM.
 // ---------------------------------------------------------------------------------
@@ -2280,6 +2455,38 @@ static int launch_regw(const void *in, int n, int H, int W, int layer, const cha
   return check_launch("conv3x3_regw");
 }
 
+// conv2_1 in f32s with register-resident (hi, lo) weights; persistent, one 8-wave block per CU
+static int launch_regw_split(const void *in, int n, int H, int W, int layer, const char *packed, void *out, hipStream_t st) {
+  constexpr int LDS = 2 * 2 * 204 * 160;  // 130 560
+  static std::atomic<bool> attr_done_dev[64];
+  std::atomic<bool> &attr_done = attr_done_dev[current_device() & 63];
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_regw_split_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+      set_error("conv3x3_regw_split: cannot raise the dynamic LDS limit to %d bytes", LDS);
+      return NQA_E_LAUNCH;
+    }
+    attr_done = true;
+  }
+  const int cus = num_cus();
+  if (!cus) {
+    set_error("conv3x3_regw_split: cannot query the device");
+    return NQA_E_LAUNCH;
+  }
+  const int cout = kConvs[layer].cout, nh = cout / 64;
+  const int tiles_x = cdiv(W, 32), tiles_y = cdiv(H, 4), total = n * tiles_x * tiles_y;
+  // the grid is a multiple of 8 XCDs x the layer's 64-channel halves (blocks of one (XCD, stream) share their tiles)
+  int streams = cus / (8 * nh);  // 16 on 256 CUs
+  if (streams > cdiv(total, 8)) streams = cdiv(total, 8);  // (an XCD owns ~ total / 8 tiles)
+  if (streams < 1) streams = 1;
+  const int grid = 8 * nh * streams;
+  const float *bias = reinterpret_cast<const float *>(packed + layer_bias_offset(layer, NQA_PREC_F32S));
+  TimedLaunch t(NQA_K_CONV, st);
+  conv3x3_regw_split_kernel<<<grid, 512, LDS, st>>>(static_cast<const char *>(in), packed + regw_offset(layer, NQA_PREC_F32S),
+                                                    bias, static_cast<char *>(out), H, W, tiles_x, tiles_y, total, cout);
+  return check_launch("conv3x3_regw_split");
+}
+
 // conv2_2 / conv3_1 (Cin 128) with register-resident weights, 16-bit modes; persistent, one 4-wave block per CU
 template <typename P, int NTERM = 1>
 static int launch_regw128(const void *in, int n, int H, int W, int layer, const char *packed, void *out, hipStream_t st,
@@ -2381,6 +2588,10 @@ static int launch_conv(const void *in, int n, int H, int W, int layer, const cha
   }
   if constexpr (!P::SPLIT) {
     if (wide) return launch_igemm<P, 2, 4, 2, 4, 32>(in, n, H, W, cs.cin, cs.cout, wpk, bias, out, out_split, st);
+  } else {
+    // conv2_1 in f32s: register-resident (hi, lo) weights (first-form bit of nqa_set_conv_variant: the implicit GEMM)
+    if (layer == 2 && blob_prec == NQA_PREC_F32S && !g_first_forms && W >= 16 && H >= 2)
+      return launch_regw_split(in, n, H, W, layer, packed, out, st);
   }
   if constexpr (sizeof(typename P::T) == 2) {
     // conv2_1: register-resident weights (first-form bit of nqa_set_conv_variant: the implicit GEMM, for A/B runs)

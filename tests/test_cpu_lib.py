@@ -101,22 +101,26 @@ def test_pack_split_f16(np_convs, lib):
     (hi + lo)/s == w to 2^-22 relative -- float32-class, where unscaled weights (~1e-2, lo subnormal) reach 2^-19."""
     from nerf_qa_amd import ops
     blob = ops.pack_vgg_weights(np_convs, "f32s").numpy()
-    # (behind the 13 layers: conv1_2 as two-term register fragments + conv1_1 as (hi, lo) MFMA fragments, for the fused
-    # f32s stage-1 kernel)
-    tail = 64 * 64 * 9 * 2 * 2 + 2 * 4 * 2 * 64 * 16
+    # (behind the 13 layers: conv1_2 and, since round 4, conv2_1 as two-term register fragments -- conv1_regw_split_kernel,
+    # conv3x3_regw_split_kernel -- + conv1_1 as (hi, lo) MFMA fragments for the fused f32s stage-1 kernel)
+    n1, n2 = 64 * 64 * 9 * 2 * 2, 128 * 64 * 9 * 2 * 2
+    tail = n1 + n2 + 2 * 4 * 2 * 64 * 16
     assert blob.nbytes == ops.pack_vgg_weights(np_convs, "f32").numpy().nbytes + tail
     # those fragments: element j of lane (l15, c4) of k-step ks = tap ks % 9 of input channel 32*(ks//9) + 8*c4 + j, output
     # channel 16*g + l15, times the layer's scale, as hi / lo halves
-    frag = blob[blob.nbytes - tail:][:64 * 64 * 9 * 4].view(np.float16).reshape(4, 2, 18, 64, 8)
-    w1 = np_convs[1][0].reshape(64, 64, 9)
     al0 = lambda v: (v + 255) // 256 * 256
     o1 = 256 + al0(27 * 64 * 4 + 64 * 4) + 6144
-    s1 = 1.0 / float(blob[o1 + al0(64 * 64 * 36):][:65 * 4].view(np.float32)[64])
-    for g, ks, lane in ((0, 0, 0), (3, 17, 63), (2, 9, 37), (1, 4, 16)):
-        co, ci0, t = 16 * g + (lane & 15), 32 * (ks // 9) + 8 * (lane >> 4), ks % 9
-        v = (w1[co, ci0:ci0 + 8, t] * np.float32(s1)).astype(np.float32)
-        assert np.array_equal(frag[g, 0, ks, lane], v.astype(np.float16))
-        assert np.array_equal(frag[g, 1, ks, lane], (v - v.astype(np.float16).astype(np.float32)).astype(np.float16))
+    o2 = o1 + al0(64 * 64 * 36) + al0(64 * 4 + 4)
+    for layer, cout, frag_off, nbytes, bias_off in ((1, 64, blob.nbytes - tail, n1, o1 + al0(64 * 64 * 36)),
+                                                    (2, 128, blob.nbytes - tail + n1, n2, o2 + al0(64 * 128 * 36))):
+        frag = blob[frag_off:][:nbytes].view(np.float16).reshape(cout // 16, 2, 18, 64, 8)
+        wl = np_convs[layer][0].reshape(cout, 64, 9)
+        sc = 1.0 / float(blob[bias_off:][:(cout + 1) * 4].view(np.float32)[cout])
+        for g, ks, lane in ((0, 0, 0), (cout // 16 - 1, 17, 63), (2, 9, 37), (1, 4, 16)):
+            co, ci0, t = 16 * g + (lane & 15), 32 * (ks // 9) + 8 * (lane >> 4), ks % 9
+            v = (wl[co, ci0:ci0 + 8, t] * np.float32(sc)).astype(np.float32)
+            assert np.array_equal(frag[g, 0, ks, lane], v.astype(np.float16))
+            assert np.array_equal(frag[g, 1, ks, lane], (v - v.astype(np.float16).astype(np.float32)).astype(np.float16))
     al = lambda v: (v + 255) // 256 * 256
     off = 256 + al(27 * 64 * 4 + 64 * 4) + 6144
     for l in (1, 4, 12):

@@ -43,7 +43,10 @@ def test_random_shape(h, w, models, oracle_convs):
     ref = dists_oracle.dists(x, y, oracle_convs, m.alpha.detach().cpu(), m.beta.detach().cpu())
     aref = adists_oracle.adists(x, y, oracle_convs)
     with torch.no_grad():
-        for key, tol in (("f32s", 5e-6), ("f32m2", 1e-4), ("f32m", 1e-4), ("f32m4", 1e-4), ("f16w", 1e-4), ("f16", 1e-4), ("bf16", 1e-3)):
+        # (f32s: 1e-7 .. 1e-6 on these frames; one 83x66 pair sits at 5-6e-6 -- tiny channel means, and whichever conv2_1
+        # kernel runs moves it by a few 1e-6 although both are within 4e-7 of a float64 convolution,
+        # tools/gpu_regw_split_check.py)
+        for key, tol in (("f32s", 1e-5), ("f32m2", 1e-4), ("f32m", 1e-4), ("f32m4", 1e-4), ("f16w", 1e-4), ("f16", 1e-4), ("bf16", 1e-3)):
             got = models[key](x.to(dev), y.to(dev)).cpu()
             assert got.shape == ref.shape and (got - ref).abs().max().item() <= tol, (key, h, w, got, ref)
         got = models["a32s"](x.to(dev), y.to(dev), as_loss=False).cpu()
