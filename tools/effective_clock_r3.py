@@ -13,7 +13,7 @@ src = sys.argv[1]
 import re
 
 CONV = ("conv3x3_igemm_kernel", "conv3x3_regw_kernel", "conv3x3_regw128_kernel", "conv1_regw_kernel",
-        "conv1_regw_split_kernel", "conv3x3_regw128_pool_kernel", "conv1_pool_kernel")  # (substring match; most specific last)
+        "conv1_regw_split_kernel", "conv3x3_regw128_pool_kernel", "conv1_pool_kernel", "conv3x3_regw_split_kernel")  # (substring match; most specific last)
 
 
 def demangle(name):  # (see summarize_profile_r3.py: rocprofv3 leaves some template instances mangled)

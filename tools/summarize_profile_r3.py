@@ -13,7 +13,7 @@ src, dst = sys.argv[1], sys.argv[2]
 os.makedirs(dst, exist_ok=True)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CONV = ("conv3x3_igemm_kernel", "conv3x3_regw_kernel", "conv3x3_regw128_kernel", "conv1_regw_kernel", "conv1_fused_kernel",
-        "conv1_tile_kernel", "conv1_regw_split_kernel", "conv3x3_regw128_pool_kernel", "conv1_pool_kernel")  # (substring match)
+        "conv1_tile_kernel", "conv1_regw_split_kernel", "conv3x3_regw128_pool_kernel", "conv1_pool_kernel", "conv3x3_regw_split_kernel")  # (substring match)
 
 
 def demangle(name):
