@@ -46,7 +46,7 @@ _DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 #     The first time a frame of a size class arrives (AUTO_CLASSES below), 256..384 synthetic pairs of that class's own
 #     sizes (additive noise at two levels, 5x5 blur, independent content) go through all six on the GPU (0.15 s for the
 #     smallest class, 4.3 s for the 1080p class).  A mode PASSES when its deviation from f32s has rms <= AUTO_F16_RMS
-#     (2e-5) AND either max <= AUTO_SAFE_MAX (2e-5: five times below the bar, whatever the tail looks like) or max <=
+#     (2e-5) AND either max <= AUTO_SAFE_MAX (1.5e-5: seven times below the bar, whatever the tail looks like) or max <=
 #     AUTO_F16_BUDGET (6e-5) with max / rms <= AUTO_TAIL (4.2: the deviations look like noise, not like outliers -- 384
 #     Gaussian samples give 3.2 +- 0.3); it is ADMITTED when it and every more accurate mode pass.
 # Why a measurement and not a rule: tools/cpu_prec_layers.py shows the 16-bit error is spread evenly over all 13
@@ -62,9 +62,11 @@ DEFAULT_PRECISION = "auto"
 AUTO_MIN_PIXELS = 128 * 128
 AUTO_F16_BUDGET = 6e-5  # on max |score_mode - score_f32s| over the calibration pairs ...
 AUTO_TAIL = 4.2         # ... and then only if max / rms looks like noise (384 Gaussian samples: 3.2 +- 0.3), not outliers;
-AUTO_SAFE_MAX = 2e-5    # a max this far below the bar is admitted whatever the shape of the tail (was 3e-5: a heavy-tailed
-#                         rung admitted at 2.6e-5 over 384 pairs reached 5.5e-5 over 1 450 unseen ones; at 2e-5 the same
-#                         factor leaves 4e-5)
+AUTO_SAFE_MAX = 1.5e-5  # a max this far below the bar is admitted whatever the shape of the tail (was 3e-5: a heavy-tailed
+#                         rung admitted at 2.6e-5 over 384 pairs reached 5.5e-5 over 1 450 unseen ones; then 2e-5 -- and
+#                         round 4's stress run on NeRF-like content took f32m4, admitted at 2.0e-5 on the gain-1.3 weights,
+#                         to 6.9e-5 over 531 unseen 1-2 Mpx pairs: a factor of 3.5.  At 1.5e-5 that factor leaves 5e-5, and
+#                         the gain-1.3 verdict no longer flips between f32m4 and f32m with the box)
 AUTO_F16_RMS = 2e-5     # on the rms, always
 # The calibration is taken PER FRAME-SIZE CLASS, at the small end of the class: the outliers of the faster modes sit in
 # single nearly-dead channels of tap 5, whose statistics run over H/16 x W/16 pixels (64 at 128x128, 8160 at 1080p), so

@@ -125,9 +125,9 @@ def test_dists_1080p_b8_vs_reference(gain, dev):
         m = DISTS(precision=prec, vgg16_path=_spec(gain)).to(dev).eval()
         if prec is None:
             chosen = m.precision_for(1080, 1920, dev)  # class 3: 224 pairs of 720p + 32 of 1080p through every rung
-            # (gain 1.3 sits between two rungs: f32m4's calibration max is 2.0-2.6e-5 against the 2e-5 admission line, so
-            # a last-bit change of the pooled maps moves the verdict between f32m4 and f32m; both hold the bar below)
-            assert chosen in {1.0: ("f16",), 1.3: ("f32m4", "f32m"), 1.6: ("f32s",)}[gain], m.calibrate(dev, 1080, 1920)
+            # (gain 1.3: f32m4's calibration max is 2.0-2.6e-5, which the 1.5e-5 safe-max clause refuses since round 4 -- it
+            # reached 6.9e-5 on unseen NeRF-like pairs -- so the verdict is f32m on every box)
+            assert chosen == {1.0: "f16", 1.3: "f32m", 1.6: "f32s"}[gain], m.calibrate(dev, 1080, 1920)
             prec = "auto->" + chosen
         with torch.no_grad():
             got = m(x, y)
