@@ -14,8 +14,10 @@ step through DISTS.forward in its shipped precision mode -- "auto": the fastest 
 f32s that the module's one-time calibration of its VGG weights admits (384 synthetic pairs through every rung; a mode is
 admitted when its deviation from f32s stays well inside the 1e-4 bar AND looks like noise rather than outliers,
 DISTS_pt.py header), per frame-size class.  For the stand-in weights used here (`synth:1234`, gain 1.0) and 1080p frames
-that is plain f16 (the smallest class, 128x128 .. 224x224, gets f16w instead); weights with ImageNet-like activation growth
-(gain 1.3) calibrate to f32m at 1080p and the stress set (gain 1.6) to f32s -- the line says what ran in `dtype`,
+that is plain f16, with stage 1 and conv2_2 pooling and summing their own taps (taps 1-2 never reach HBM at full
+resolution; every frame below 0.9 Mpx runs f32s by default since the calibration has NeRF-like content); weights with
+ImageNet-like activation growth (gain 1.3) calibrate to f32m at 1080p and the stress set (gain 1.6) to f32s -- the line
+says what ran in `dtype`,
 `config.precision`, `config.auto_calibration`, and carries the other two defaults as companions.  Frames are resident in HBM.  Frames
 shard across ranks with no data-path collective; the only exchange is ONE all-gather of the per-frame scores
 after the last step (inside the timed region) -- weak scaling, K steps of 8 pairs on every GPU.
@@ -31,8 +33,10 @@ products; peak 157.3 TF), 256x256 B=32 (configs[1]) in f16 / f32m / f32s, and A-
 `roofline` (the MFMA conv stack: algorithmic FLOPs of layers 1..12 / the HIP-event time of those launches, measured
 inside the timed region on the launch stream; `peak` is always the guide's dense 2.5 PFLOP/s f16 figure, and for
 f32m / f32s both the algorithmic and the issued-MFMA fraction are given) and `roofline_hbm` (the HBM-bound L2-pool +
-statistics pass).  `roofline.traffic` comes from the committed rocprofv3 PMC summary of this same command
-(profiles/r03_traffic.json), per launch, and is withheld when the library that ran is not the profiled build.
+statistics pass over the taps the conv kernels do not close themselves -- `fused_taps` names the others -- against
+the guide's 8 TB/s and against the best hand-written stream of the same read / write mix).  `roofline.traffic` comes
+from the committed rocprofv3 PMC summary of this same command (profiles/r04_traffic.json), per launch, and is withheld
+when the library that ran is not the profiled build.
 
 `--workload video10k` is BASELINE.json configs[3]: a 10 000-frame 1080p video whose frames are generated on
 the device per batch from seed = frame index, sharded over the ranks (strong scaling), one all-gather.
