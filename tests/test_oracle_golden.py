@@ -144,3 +144,28 @@ def test_oracle_matches_nerf_like_goldens(path):
     assert np.abs(dists_oracle.dists(x, y, convs, a, b).numpy() - g["score"][:4]).max() <= 2e-6
     assert np.abs(adists_oracle.adists(x[:2], y[:2], convs, as_loss=False).numpy() - g["adists"][:2]).max() <= 2e-6
     assert (g["dead_frac"] > 0.01).all()  # the family does what it is for: exactly dead channels in every tap
+
+
+def test_adists_torch_head_matches_the_oracle_values_and_gradients(oracle_convs):
+    """nerf_qa_amd/ADISTS/head.py (the differentiable head behind ADISTS(as_loss=True) under autograd) against the oracle's
+    head on the oracle's own pyramids, on the CPU: the value of 1 - mean(D) and its gradient towards both images.  (The
+    window means are sums of shifted slices there, not F.conv2d; windowed and global-fallback stages both occur.)"""
+    from nerf_qa_amd import synth
+    from nerf_qa_amd.ADISTS import head
+    from oracle import adists_oracle as ao
+    from oracle import dists_oracle as do
+    xn, yn = synth.frame_batch([31, 32], 48, 60, ["blur", "noise10"])
+    xa, ya = torch.from_numpy(xn).requires_grad_(), torch.from_numpy(yn).requires_grad_()
+    ref = ao.adists_from_feats(do.vgg_pyramid(xa, oracle_convs), do.vgg_pyramid(ya, oracle_convs), as_loss=True)
+    gref = torch.autograd.grad(ref, [xa, ya])
+    xb, yb = torch.from_numpy(xn).requires_grad_(), torch.from_numpy(yn).requires_grad_()
+    mine = 1 - head.adists_d(do.vgg_pyramid(xb, oracle_convs), do.vgg_pyramid(yb, oracle_convs), 21).mean()
+    gm = torch.autograd.grad(mine, [xb, yb])
+    assert abs(mine.item() - ref.item()) <= 2e-7
+    for a, b in zip(gm, gref):
+        assert (a - b).abs().max().item() <= 1e-4 * b.abs().max().item()
+    # per-pair D, the as_loss=False expression
+    with torch.no_grad():
+        d = 1 - head.adists_d(do.vgg_pyramid(xb, oracle_convs), do.vgg_pyramid(yb, oracle_convs), 21)
+        want = ao.adists(torch.from_numpy(xn), torch.from_numpy(yn), oracle_convs)
+    assert (d - want).abs().max().item() <= 2e-7
