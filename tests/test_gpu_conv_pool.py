@@ -190,3 +190,29 @@ def test_dists_forward_fused_stage1_equals_unfused(h, w, b, dev):
         assert es <= 2e-5, (name, es)
         assert t1 <= 1e-5 and t2 <= 1e-3, (name, t1, t2)
     assert torch.equal(out["fused"][1][:, :3], out["unfused"][1][:, :3])  # tap 0 (the raw image) is untouched
+
+
+@pytest.mark.parametrize("n,h,w", [(2, 97, 131), (4, 49, 66), (3, 42, 33)], ids=["2x97x131", "4x49x66", "3x42x33"])
+def test_repeated_launches_are_bit_equal_on_ragged_maps(n, h, w, dev, blobs):
+    """The persistent LDS-DMA kernels of round 4 (conv2_1 in f32s with register weights, the two fused conv + pool +
+    statistics kernels) launched ten times on ragged maps whose blocks own one or two tiles each: bit-equal outputs.  (How a
+    DMA lane that addressed LDS behind its slot showed itself: single wrong pixels in about every second launch.)"""
+    from nerf_qa_amd import ops, synth
+    g = torch.Generator(device=dev).manual_seed(n * 1000 + h)
+    # conv2_1, f32s: split16 in, split16 out
+    packed32 = ops.pack_vgg_weights(synth.vgg16_weights(1234), "f32s").to(dev)
+    a = ops.split16_encode((torch.rand(n, h, w, 64, device=dev, generator=g) * 4 - 1).clamp_min(0))
+    first = ops.conv3x3_relu(a, 2, packed32, "f32s").view(torch.int32).clone()
+    for _ in range(10):
+        assert torch.equal(first, ops.conv3x3_relu(a, 2, packed32, "f32s").view(torch.int32))
+    # the fused stage 1 and the fused conv2_2 (f16)
+    x = torch.rand(n, 3, 2 * h, 2 * w, device=dev, generator=g)
+    y = (0.5 * x + 0.5 * torch.rand(x.shape, device=dev, generator=g)).clamp_(0, 1)
+    p1, s1 = ops.conv1_pool_stats(x, y, blobs["f16"], "f16")
+    t = (torch.rand(2 * n, h, w, 128, device=dev, generator=g) * 2 - 0.5).clamp_min(0).half()
+    p2, s2 = ops.conv_pool_stats(t, 3, blobs["f16"], "f16")
+    p1, s1, p2, s2 = p1.clone(), s1.clone(), p2.clone(), s2.clone()
+    for _ in range(10):
+        q1, r1 = ops.conv1_pool_stats(x, y, blobs["f16"], "f16")
+        q2, r2 = ops.conv_pool_stats(t, 3, blobs["f16"], "f16")
+        assert torch.equal(p1, q1) and torch.equal(s1, r1) and torch.equal(p2, q2) and torch.equal(s2, r2)
