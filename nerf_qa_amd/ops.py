@@ -185,17 +185,24 @@ def nhwc_to_nchw_f32(inp: torch.Tensor, prec) -> torch.Tensor:
 
 class Workspace:
     """Grow-only device scratch, one buffer per (module, device, HIP stream): avoids allocator traffic per call, and two
-    streams that run the same module side by side (ADISTS' two half-batches) never share scratch."""
+    streams that run the same module side by side (ADISTS' two half-batches) never share scratch.  At most MAX_STREAMS
+    buffers are kept (the least recently used one goes first): a caller that scores from many short-lived streams does
+    not pile up gigabytes of scratch."""
+
+    MAX_STREAMS = 8
 
     def __init__(self):
         self.bufs = {}
 
     def get(self, nbytes: int, dev: torch.device) -> torch.Tensor:
         key = (str(dev), torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0)
-        buf = self.bufs.get(key)
+        buf = self.bufs.pop(key, None)
         if buf is None or buf.numel() < nbytes:
-            self.bufs[key] = buf = None  # (released before the larger one is requested)
-            self.bufs[key] = buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
+            buf = None  # (released before the larger one is requested)
+            while len(self.bufs) >= self.MAX_STREAMS:
+                self.bufs.pop(next(iter(self.bufs)))
+            buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
+        self.bufs[key] = buf  # (re-inserted: most recently used last)
         return buf
 
 

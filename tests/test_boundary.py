@@ -167,3 +167,19 @@ def test_adists_as_loss_never_returns_a_silent_graphless_scalar():
         m(x, torch.rand(1, 3, 32, 32))
     with pytest.raises(nerf_qa_amd.NqaError):
         m(torch.rand(1, 3, 32, 32), x, as_loss=True)
+
+
+def test_workspace_is_per_stream_and_capped():
+    """ops.Workspace: one grow-only buffer per (device, stream) -- on the CPU one key -- and never more than MAX_STREAMS of
+    them (least recently used first out)."""
+    from nerf_qa_amd import ops
+    w, cpu = ops.Workspace(), torch.device("cpu")
+    a = w.get(100, cpu)
+    assert w.get(50, cpu) is a and a.numel() == 256 and len(w.bufs) == 1
+    b = w.get(4096, cpu)
+    assert b.numel() == 4096 and len(w.bufs) == 1 and w.get(4096, cpu) is b
+    for k in range(20):  # (stand-ins for twenty short-lived streams)
+        w.bufs[("cpu", 1000 + k)] = torch.empty(1, dtype=torch.uint8)
+        w.bufs.pop(("cpu", 0), None)
+        w.get(256, cpu)
+    assert len(w.bufs) <= ops.Workspace.MAX_STREAMS + 1
