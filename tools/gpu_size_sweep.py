@@ -9,11 +9,13 @@ dev = torch.device("cuda:0")
 with warnings.catch_warnings():
     warnings.simplefilter("ignore")
     d, a = DISTS().to(dev).eval(), ADISTS().to(dev).eval()
-for (H, W, B) in ((256, 256, 32), (512, 512, 16), (720, 1280, 8), (1080, 1920, 8), (2160, 3840, 2)):
+    d16 = DISTS(precision="f16").to(dev).eval()
+for (H, W, B) in ((256, 256, 32), (512, 512, 16), (800, 800, 8), (720, 1280, 8), (1080, 1920, 8), (2160, 3840, 2)):
     x = torch.rand(B, 3, H, W, device=dev)
     y = (x + 0.1 * torch.randn_like(x)).clamp(0, 1)
     row = f"{H}x{W} B={B}:"
-    for name, fn in (("DISTS", lambda: d(x, y)), ("A-DISTS", lambda: a(x, y, as_loss=False))):
+    for name, fn in ((f"DISTS auto->{d.precision_for(H, W, dev)}", lambda: d(x, y)), ("DISTS f16", lambda: d16(x, y)),
+                     ("A-DISTS", lambda: a(x, y, as_loss=False))):
         with torch.no_grad():
             for _ in range(3):
                 fn()
