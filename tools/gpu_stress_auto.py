@@ -41,16 +41,16 @@ def frames(g, rng, h, w):
             r = int(rng.choice([1, 2]))
             obj = 0.5 * x + 0.5 * F.avg_pool2d(x, 2 * r + 1, 1, r, count_include_pad=False) \
                 + float(rng.uniform(0.0, 0.05)) * torch.randn(1, 3, h, w, device=dev, generator=g)
-            return (m * x + (1 - m) * bg).clamp_(0, 1), (m2 * obj + (1 - m2) * bg).clamp_(0, 1), "nerf"
+            return (m * x + (1 - m) * bg).clamp_(0, 1), (m2 * obj + (1 - m2) * bg).clamp_(0, 1), "nerf: object on constant bg"
         if k == 8:  # smooth everywhere, render slightly brighter / softer
             xs = low * float(rng.uniform(0.4, 0.9)) + float(rng.uniform(0.0, 0.1))
             ys = F.avg_pool2d(xs, 5, 1, 2, count_include_pad=False) * float(rng.uniform(0.9, 1.1)) + float(rng.uniform(-0.03, 0.03))
-            return xs.clamp_(0, 1), ys.clamp_(0, 1), "nerf"
+            return xs.clamp_(0, 1), ys.clamp_(0, 1), "nerf: smooth everywhere"
         col = torch.rand(1, 3, 1, 1, device=dev, generator=g) * 0.6 + 0.2  # k == 9: a flat frame and floaters
         xs = (col + 0.05 * (low - 0.5)).clamp_(0, 1)
         blob = ((field - float(rng.uniform(0.8, 0.9))) * 60.0).clamp(0, 1)
         ys = ((1 - blob) * xs + blob * torch.rand(1, 3, 1, 1, device=dev, generator=g)).clamp_(0, 1)
-        return xs, ys, "nerf"
+        return xs, ys, "nerf: flat + floaters"
     if k == 0:
         y = x + float(rng.uniform(0.005, 0.15)) * torch.randn(1, 3, h, w, device=dev, generator=g)
     elif k == 1:
@@ -98,6 +98,6 @@ for gain in GAINS:
         print(f"gain {gain} class {c} (>= {frm} px, auto -> {mode}): {len(v)} pairs  max {v.max():.2e} (at {wd[1]}x{wd[2]})  "
               f"p99 {np.quantile(v, 0.99):.2e}  rms {np.sqrt((v * v).mean()):.2e}", flush=True)
         worst_overall = max(worst_overall, v.max())
-        print("      by content family: " + ", ".join(f"{f}: {len(fam[(c, f)])} pairs max {max(fam[(c, f)]):.2e}" for f in ("texture", "nerf") if (c, f) in fam), flush=True)
+        print("      by content family: " + ", ".join(f"{f}: {len(fam[(c, f)])} pairs max {max(fam[(c, f)]):.2e}" for f in ("texture", "nerf: object on constant bg", "nerf: smooth everywhere", "nerf: flat + floaters") if (c, f) in fam), flush=True)
 print(f"worst |auto - f32s| over everything: {worst_overall:.2e}")
 assert worst_overall <= 1e-4
