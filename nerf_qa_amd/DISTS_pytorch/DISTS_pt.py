@@ -68,6 +68,16 @@ AUTO_SAFE_MAX = 1.5e-5  # a max this far below the bar is admitted whatever the 
 #                         to 6.9e-5 over 531 unseen 1-2 Mpx pairs: a factor of 3.5.  At 1.5e-5 that factor leaves 5e-5, and
 #                         the gain-1.3 verdict no longer flips between f32m4 and f32m with the box)
 AUTO_F16_RMS = 2e-5     # on the rms, always
+# The content guard of `auto` (round 4): a pair whose reference OR rendered frame is nearly flat -- pixel variance (mean over
+# the colour planes) below AUTO_FLAT_VAR, i.e. a standard deviation under ~4.5 % of the range: fog, a blank wall, an empty
+# render -- is rescored in f32s whatever rung its size class calibrated to.  On such frames almost every VGG channel has a
+# tiny variance and S2 is a quotient of two tiny moments in all 1 475 of them: tools/gpu_flat_frames.py has plain f16 at
+# 6-9e-5 (once 1.45e-4) and f32m at 4-8e-5 from f32s for one colour +- 0 .. 10 % of smooth variation against a render with
+# floaters, at 1.5 Mpx, where texture-rich content stays below 3.6e-5 / 1.5e-5; the 6 000-pair stress run's worst case
+# (7.0e-5) is this family too.  No calibration family can stand for it without costing everyone the fast rungs; the guard
+# costs two small reductions over a sixteenth of the pixels and one host look at the result per call (0 disables it:
+# NQA_AUTO_FLAT_VAR=0).  Natural frames have a pixel variance of 0.02 .. 0.08.
+AUTO_FLAT_VAR = float(os.environ.get("NQA_AUTO_FLAT_VAR", "2e-3"))
 # The calibration is taken PER FRAME-SIZE CLASS, at the small end of the class: the outliers of the faster modes sit in
 # single nearly-dead channels of tap 5, whose statistics run over H/16 x W/16 pixels (64 at 128x128, 8160 at 1080p), so
 # what 128x128 frames refuse, 1080p frames may well allow (tools/gpu_size_study.py, tools/gpu_outlier_study.py).
@@ -279,6 +289,7 @@ class DISTS(torch.nn.Module):
             prec_id(self.precision)  # validate early
         self._packed = {}
         self._ws = ops.Workspace()
+        self._guard_streams = {}
         self._auto = None  # (weights key, {size class: report}) once calibrated
         self._deltas = {}  # {size class: {mode: (dS1, dS2)}} similarity deviations, kept for _live_choice only
         self._agreed = {}  # {size class: (weights key, mode)} set by sharding.agree_precision under a process group
@@ -481,6 +492,7 @@ class DISTS(torch.nn.Module):
         d = self.__dict__.copy()
         d.pop("_packed", None)
         d.pop("_ws", None)  # (__setstate__ rebuilds both)
+        d.pop("_guard_streams", None)
         d["_auto"] = None
         for k in ("_deltas", "_agreed"):
             d[k] = {}
@@ -497,6 +509,7 @@ class DISTS(torch.nn.Module):
         d.setdefault("precision", os.environ.get("NQA_PRECISION", DEFAULT_PRECISION))
         d.setdefault("vgg_source", "unpickled module (Conv2d weights of stage1..5)")
         d["_packed"], d["_ws"], d["_auto"], d["_deltas"], d["_agreed"] = {}, ops.Workspace(), None, {}, {}
+        d["_guard_streams"] = {}
 
     def _similarities(self, x, y, require_grad=False):
         if x.shape != y.shape:
@@ -506,7 +519,37 @@ class DISTS(torch.nn.Module):
             from ..autograd import DistsSimilarities
             return DistsSimilarities.apply(x, y, self)
         prec = self.precision_for(x.shape[-2], x.shape[-1], x.device)
-        return ops.dists_forward(x, y, self._packed_weights(x.device, prec), prec, self._ws)
+        if self.precision != "auto" or prec == "f32s" or AUTO_FLAT_VAR <= 0.0:
+            return ops.dists_forward(x, y, self._packed_weights(x.device, prec), prec, self._ws)
+        # `auto` on a fast rung: nearly FLAT frames are rescored in f32s (see AUTO_FLAT_VAR).  The flatness of the pairs is
+        # measured on a SIDE stream (behind an event that says "x and y are ready") and copied to pinned host memory, the
+        # fast forward is enqueued on the caller's stream meanwhile, and the host waits for the side stream only: the
+        # caller's stream never drains, so the guard costs a few microseconds of host time per call.
+        dev = x.device
+        side = self._guard_streams.get(str(dev))
+        if side is None:
+            side = self._guard_streams[str(dev)] = torch.cuda.Stream(dev)
+        main = torch.cuda.current_stream(dev)
+        ready, done = torch.cuda.Event(), torch.cuda.Event()
+        ready.record(main)
+        flat_host = torch.empty(x.shape[0], dtype=torch.bool, pin_memory=True)
+        with torch.no_grad(), torch.cuda.stream(side):
+            side.wait_event(ready)
+            # (every sixteenth row of both frames, whole rows so that the reduction reads contiguous memory: 1 / 16 of the
+            # pixels tells flat from not)
+            rows = torch.stack([x[:, :, ::16], y[:, :, ::16]]).float()
+            flat = rows.var(dim=(3, 4)).mean(dim=2).amin(dim=0) < AUTO_FLAT_VAR
+            flat_host.copy_(flat, non_blocking=True)
+            done.record(side)
+        s1, s2 = ops.dists_forward(x, y, self._packed_weights(x.device, prec), prec, self._ws)
+        done.synchronize()
+        idx = flat_host.nonzero().flatten().to(dev)
+        if idx.numel():
+            e1, e2 = ops.dists_forward(x[idx].contiguous(), y[idx].contiguous(), self._packed_weights(x.device, "f32s"), "f32s",
+                                       self._ws)
+            s1.index_copy_(0, idx, e1)
+            s2.index_copy_(0, idx, e2)
+        return s1, s2
 
     def _weighted(self, s1, s2, batch_average):
         """score from S1,S2; DISTS_pt.py:123-148."""

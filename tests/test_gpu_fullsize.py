@@ -149,3 +149,31 @@ def test_oversized_frame_is_refused(dev):
     x = torch.zeros(1, 3, 4096, 8192, device=dev)  # 33.5 M pixels: H*W*64*2 >= 2^31
     with pytest.raises(_lib.NqaError):
         ops.dists_forward(x, x, torch.zeros(16, dtype=torch.uint8, device=dev), "f16")
+
+
+def test_auto_rescoring_of_nearly_flat_frames(dev, monkeypatch):
+    """`auto` on a fast rung (720p, gain-1.0 stand-ins: f16) rescoring the pairs whose reference or rendered frame is nearly flat
+    in f32s (DISTS_pt.AUTO_FLAT_VAR): those pairs carry the f32s scores, the others the fast rung's, and with the guard off
+    everything is the fast rung's."""
+    from nerf_qa_amd.DISTS_pytorch import DISTS
+    from nerf_qa_amd.DISTS_pytorch import DISTS_pt as dp
+    H, W = 720, 1280
+    g = torch.Generator(device=dev).manual_seed(11)
+    x = torch.rand(4, 3, H, W, device=dev, generator=g)
+    y = (x + 0.05 * torch.randn(x.shape, device=dev, generator=g)).clamp_(0, 1)
+    low = torch.nn.functional.interpolate(torch.rand(1, 3, 45, 80, device=dev, generator=g), size=(H, W), mode="bilinear")
+    x[1] = 0.4 + 0.02 * (low[0] - 0.5)                     # a nearly flat reference frame ...
+    y[1] = x[1]
+    y[1, :, 300:340, 500:560] = 0.9                        # ... against a render with a floater
+    y[3] = 0.6 + 0.01 * (low[0] - 0.5)                     # a textured reference against a nearly flat render
+    auto = DISTS(vgg16_path="synth:1234").to(dev).eval()
+    f16 = DISTS(vgg16_path="synth:1234", precision="f16").to(dev).eval()
+    f32s = DISTS(vgg16_path="synth:1234", precision="f32s").to(dev).eval()
+    assert auto.precision_for(H, W, dev) == "f16" and dp.AUTO_FLAT_VAR == 2e-3
+    with torch.no_grad():
+        a, fast, exact = auto(x, y), f16(x, y), f32s(x, y)
+        assert torch.equal(a[[0, 2]], fast[[0, 2]])                        # textured pairs: the fast rung, untouched
+        assert (a[[1, 3]] - exact[[1, 3]]).abs().max().item() <= 3e-7      # flat ones: f32s (another batch split: 1e-7)
+        assert (fast[[1, 3]] - exact[[1, 3]]).abs().max().item() > 3e-7   # (which is not what f16 gives them)
+        monkeypatch.setattr(dp, "AUTO_FLAT_VAR", 0.0)
+        assert torch.equal(auto(x, y), fast)
