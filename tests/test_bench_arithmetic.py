@@ -72,3 +72,17 @@ def test_hbm_roofline_prices_only_the_taps_that_still_go_through_pool_stats():
     assert hbm["fused_taps"] == [1, 2] and hbm["launches"] == 4 and hbm["seam_launches"] == 4
     assert abs(hbm["achieved"] - rest * 16 * 2 / 1.2e-3 / 1e9) < 1.0 and hbm["bytes_per_launch_avg"] == round(rest * 16 / 2)
     assert abs(kms["conv_igemm"] - 17.0) < 1e-9 and roof["launches"] == 24
+
+
+def test_roofline_of_a_step_run_as_two_half_batches():
+    """A-DISTS runs a batch as two half-batches on two streams: 24 conv launches per step.  With the step count given the
+    FLOPs are those of ONE pyramid pass over the batch per step (inferring the steps from the launches doubled them)."""
+    b = _bench()
+    kt = {"conv1_1": (0, 0.0), "conv_igemm": (48, 96.0), "l2pool": (16, 9.0), "stats": (8, 0.3), "adists": (40, 36.0),
+          "prep": (0, 0.0), "pool_seam": (0, 0.0)}
+    roof, hbm, kms = b.rooflines(kt, 1080, 1920, 8, "f32s", {}, fused=(), steps=2)
+    flops = b.conv_flops_per_image(1080, 1920)[0] * 16 * 2
+    assert abs(roof["achieved"] - flops / 96e-3 / 1e12) < 0.01 and abs(kms["conv_igemm"] - 48.0) < 1e-9
+    assert roof["flop_per_launch_avg"] == round(flops / 2 / 24)
+    inferred, _, _ = b.rooflines(kt, 1080, 1920, 8, "f32s", {}, fused=())
+    assert abs(inferred["achieved"] - 2 * roof["achieved"]) < 0.02  # (what the line said before the count was passed in)
