@@ -526,6 +526,10 @@ class DISTS(torch.nn.Module):
         # fast forward is enqueued on the caller's stream meanwhile, and the host waits for the side stream only: the
         # caller's stream never drains, so the guard costs a few microseconds of host time per call.
         dev = x.device
+        if torch.cuda.is_current_stream_capturing():
+            raise NqaError("DISTS(precision='auto') on a fast rung looks at the frames on the host (nearly flat frames are "
+                           "rescored in f32s) and cannot be captured into a hipGraph: name the precision "
+                           f"(precision={prec!r} is what this frame size calibrated to) or set NQA_AUTO_FLAT_VAR=0")
         side = self._guard_streams.get(str(dev))
         if side is None:
             side = self._guard_streams[str(dev)] = torch.cuda.Stream(dev)

@@ -35,3 +35,36 @@ def test_forward_captures_into_a_hip_graph_and_replays(metric):
             got = out.clone()
             want = call(a, b)
             assert torch.equal(got, want), (metric, (got - want).abs().max().item())
+
+
+def test_guarded_auto_forward_refuses_capture_and_a_named_precision_captures():
+    """`auto` on a fast rung looks at the frames on the host (nearly flat ones are rescored in f32s): under stream capture it
+    says so instead of failing inside the capture; the same frame size with the precision named captures and replays."""
+    import nerf_qa_amd
+    from nerf_qa_amd.DISTS_pytorch import DISTS
+    dev = torch.device("cuda:0")
+    auto = DISTS(vgg16_path="synth:1234").to(dev).eval()
+    assert auto.precision_for(720, 1280, dev) == "f16"
+    f16 = DISTS(vgg16_path="synth:1234", precision="f16").to(dev).eval()
+    gen = torch.Generator(device=dev).manual_seed(9)
+    x = torch.rand(1, 3, 720, 1280, device=dev, generator=gen)
+    y = (x + 0.05 * torch.randn(x.shape, device=dev, generator=gen)).clamp_(0, 1)
+    with torch.no_grad():
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            want = auto(x, y)
+            f16(x, y)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        g1 = torch.cuda.CUDAGraph()
+        with pytest.raises(nerf_qa_amd.NqaError, match="hipGraph"):
+            with torch.cuda.graph(g1):
+                auto(x, y)
+        del g1
+        torch.cuda.synchronize(dev)
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2):
+            out = f16(x, y)
+        g2.replay()
+        torch.cuda.synchronize(dev)
+        assert torch.equal(out, want)  # (a textured frame: the guard leaves the fast rung's score alone)
